@@ -1,0 +1,142 @@
+/* rt_hip.h -- C-ABI of the MI355X render layer beyond the reference's own
+ * entry points (rt_raytracer.h).  Plain pointers and sizes only.
+ *
+ * The reference has no device layer; these calls are what its driver would use
+ * to control one (seed, device choice, error text, explicit scene residency)
+ * and what a multi-process launcher needs to render a subset of the 32x32
+ * chunks of raytracer.c:601-627 on each GPU.  INTEGRATION.md shows the
+ * reference-side stubs.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include "rt_raytracer.h"
+#include "rt_materials.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Text of the most recent failure in this process ("" when none).  The render
+ * entry points are void in the reference (raytracer.h:51-56), so errors are
+ * reported here and on stderr. */
+extern char const *rt_last_error(void);
+extern void        rt_clear_error(void);
+
+/* Selects the HIP device for this process (default 0).  0 on success. */
+extern int rt_init(int device);
+
+/* Frame seed of the per-path RNG rule rt_path_seed() (rt_math.h); replaces
+ * `random_state = time_now()` of raytracer.c:597.  Default 0x1234ABCD. */
+extern void rt_set_seed(u32 seed);
+extern u32  rt_get_seed(void);
+
+/* ---- scene residency ------------------------------------------------------- */
+
+typedef struct RT_Device_Scene RT_Device_Scene;
+
+/* Flattens a host Scene into HBM: BVH nodes, per-leaf SoA tiles, trimmed AoS
+ * records with material ids, the material table, and every Image referenced by
+ * a material or by the background (RGB8/RGBA8 -> RGBA8).  Fails (NULL +
+ * rt_last_error) on a shader/background proc that is not one of the exported
+ * tokens of rt_materials.h.  render_thread_proc() calls this itself and caches
+ * the result per Scene*; rt_scene_invalidate() drops that cache entry after the
+ * host Scene was modified. */
+extern RT_Device_Scene *rt_scene_upload(Scene const *scene);
+extern void             rt_scene_release(RT_Device_Scene *dscene);
+extern void             rt_scene_invalidate(Scene const *scene);
+extern i64              rt_scene_device_bytes(RT_Device_Scene const *dscene);
+
+/* Camera used by rt_render_accumulate() for an explicitly uploaded scene;
+ * rt_scene_upload() captures scene->camera, this replaces it. */
+extern int rt_set_camera(RT_Device_Scene *dscene, Camera const *camera);
+
+/* ---- rendering -------------------------------------------------------------- */
+
+typedef struct {
+  u64 paths;        /* camera paths started                               */
+  u64 rays;         /* ray_scene_hit equivalents (raytracer.c:514)        */
+  u64 node_visits;  /* 8-box slab tests (raytracer.c:452)                 */
+  u64 leaf_visits;  /* 8-triangle tests (raytracer.c:476)                 */
+  u64 shades;       /* material evaluations (raytracer.c:535)             */
+  u64 backgrounds;  /* environment lookups (raytracer.c:554)              */
+  u64 textured;     /* shades on a material with at least one texture     */
+} RT_Counters;
+
+typedef struct {
+  i32 width, height;     /* image size                                          */
+  i32 samples;           /* samples per pixel (Rendering_Context.samples)       */
+  i32 max_bounces;       /* Rendering_Context.max_bounces                       */
+  u32 seed;              /* frame seed                                          */
+  i32 rank, world;       /* this process renders chunk c iff c % world == rank  */
+  i32 slab;              /* samples per work item (0 = library default)         */
+  i32 flags;             /* RT_FLAG_*                                           */
+} RT_Render_Params;
+
+enum {
+  RT_FLAG_NONE = 0,
+};
+
+/* Number of 32x32 chunks of a width x height image, and how many of them
+ * `rank` owns under the interleaved partition. */
+extern i32 rt_chunk_count(i32 width, i32 height);
+extern i32 rt_local_chunk_count(i32 width, i32 height, i32 rank, i32 world);
+
+/* Renders this rank's chunks.  All pointers are DEVICE pointers owned by the
+ * caller, `stream` is a hipStream_t (NULL = default stream); the call only
+ * enqueues work.
+ *   d_accum  : u64[height*width*3] fixed-point radiance sums (rt_math.h), must
+ *              be zero on entry for the chunks this rank owns
+ * 0 on success. */
+extern int rt_render_accumulate(RT_Device_Scene *dscene, RT_Render_Params const *params,
+                                void *d_accum, void *stream);
+
+/* accum -> mean radiance -> clamp -> sRGB -> u8 (raytracer.c:700-716) for this
+ * rank's chunks.
+ *   d_tiles  : u8[n_local_chunks*32*32*3], chunk-major compact tiles, or NULL
+ *   d_image  : u8[height*width*3] row-major image, or NULL
+ *   d_linear : f32[height*width*3] mean radiance before clamp, or NULL */
+extern int rt_resolve(RT_Render_Params const *params, void const *d_accum,
+                      void *d_tiles, void *d_image, void *d_linear, void *stream);
+
+/* Scatters gathered compact tiles of ALL ranks (rank-major:
+ * [world][max_local_chunks][32*32*3]) into a row-major u8 image on the device. */
+extern int rt_untile(i32 width, i32 height, i32 world, void const *d_all_tiles,
+                     void *d_image, void *stream);
+
+/* Whole frame from host memory to host memory on one GPU: upload/cached scene,
+ * accumulate, resolve, copy back.  pixels: u8[height*stride*components] as the
+ * reference lays out Image; linear (optional): f32[height*width*3];
+ * accum (optional): u64[height*width*3].  0 on success. */
+extern int rt_render_frame(Scene const *scene, Image const *image, isize samples, isize max_bounces,
+                           f32 *linear, u64 *accum);
+
+/* Counters of the last rt_render_accumulate / rt_render_frame on this process
+ * (read back synchronously). */
+extern int rt_get_counters(RT_Counters *out);
+
+/* GPU time of the most recent path-tracing kernel launch in milliseconds
+ * (HIP events on the launch stream); negative if none.  Synchronises. */
+extern f32 rt_last_kernel_ms(void);
+
+/* ---- unit-level device entry points (parity tests call the same device
+ * functions the render kernel uses) ------------------------------------------ */
+
+/* rt_math.h on the GPU; op codes as oracle_math() (oracle/oracle.h).  Host
+ * pointers. */
+extern int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
+
+/* Closest hit of n rays (host arrays, 6 f32 per ray: origin, direction) against
+ * an uploaded scene: out_t[n], out_tri[n] (-1 = miss), out_uv[2n]. */
+extern int rt_test_trace(RT_Device_Scene *dscene, i32 n, f32 const *rays,
+                         f32 *out_t, i32 *out_tri, f32 *out_uv);
+
+/* Bilinear fetch (driver.c:49-93) of n (u,v) pairs on texture `tex` of the
+ * uploaded scene (index in upload order; -1 = background image). */
+extern int rt_test_texture(RT_Device_Scene *dscene, i32 tex, i32 n, f32 const *uv, f32 *out_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_HIP_H */

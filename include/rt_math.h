@@ -1,0 +1,277 @@
+/* rt_math.h -- the numeric contract of the render path, single source for the
+ * host C compiler and for hipcc (gfx950 device code).
+ *
+ * The reference leans on an absent third-party library for every scalar math
+ * call on the path (codin `linalg.h`: vec3_normalize / vec3_lerp /
+ * vec3_reflect; codin math wrappers: pow_f32, sin_f32, cos_f32, atan2_f32,
+ * asin_f32, sqrt_f32 -- call sites common.h:84-91, driver.c:99-100,122-123,
+ * 239-240, raytracer.c:526) and ships no tests, so their ulp-level behaviour is
+ * unpinned.  This header defines it ONCE, using only
+ * operations that IEEE-754 rounds identically on x86-64 and gfx950:
+ *   + - * /  sqrt  floor  int<->float conversion  comparisons  bit casts.
+ * Both compilers MUST be run with -ffp-contract=off and without fast-math
+ * (hipcc additionally keeps its default correctly rounded fp32 divide/sqrt);
+ * then every function below returns bit-identical results on CPU and GPU, which
+ * is what lets tests/ demand bit-exact images instead of a tolerance.
+ *
+ * Polynomial coefficients are the classic single-precision minimax sets
+ * (Cephes, S. Moshier) for log/exp/sin/cos/atan/asin.
+ */
+#ifndef RT_MATH_H
+#define RT_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RT_FN __host__ __device__ static inline __attribute__((always_inline))
+#else
+#define RT_FN static inline __attribute__((always_inline))
+#endif
+
+#define RT_PI      3.14159265358979323846f
+#define RT_EPS     0.0001f                       /* common.h:8 */
+#define RT_INF     __builtin_inff()
+
+typedef struct { float x, y, z; } rt_v3;
+typedef struct { float x, y; } rt_v2;
+
+/* ---- bit casts / basic selects --------------------------------------------- */
+
+RT_FN uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RT_FN float    rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+/* _mm256_min_ps / _mm256_max_ps operand semantics (raytracer.c:212-225): the
+ * SECOND operand is returned when either one is NaN. */
+RT_FN float rt_min_ps(float a, float b) { return a < b ? a : b; }
+RT_FN float rt_max_ps(float a, float b) { return a > b ? a : b; }
+
+RT_FN float rt_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+RT_FN float rt_absf(float x) { return rt_u2f(rt_f2u(x) & 0x7fffffffu); }
+RT_FN float rt_sqrtf(float x) { return __builtin_sqrtf(x); }
+RT_FN float rt_floorf(float x) { return __builtin_floorf(x); }
+RT_FN float rt_fractf(float x) { return x - rt_floorf(x); }   /* raytracer.c:582 */
+
+/* ---- RNG (common.h:13-24) --------------------------------------------------- */
+
+/* One step of the reference generator: returns the new state. */
+RT_FN uint32_t rt_pcg(uint32_t v) {
+  uint32_t state = v * 747796405u + 2891336453u;
+  uint32_t word  = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+
+RT_FN uint32_t rt_rand_u32(uint32_t *state) {
+  *state = rt_pcg(*state);
+  return *state;
+}
+
+/* rand_u32() / (f32)U32_MAX; (f32)U32_MAX rounds to 2^32, the result lies in
+ * [0, 1] INCLUSIVE (common.h:22-24). */
+RT_FN float rt_rand_f32(uint32_t *state) {
+  return (float)rt_rand_u32(state) / 4294967296.0f;
+}
+
+/* Per-path seeding rule of this build (replaces the wall-clock, per-thread
+ * seeding of raytracer.c:597 -- SURVEY.md F4/H2): the stream of one path
+ * depends only on (frame seed, pixel index, sample index). */
+RT_FN uint32_t rt_path_seed(uint32_t seed, uint32_t pixel_index, uint32_t sample) {
+  return rt_pcg(rt_pcg(seed ^ pixel_index) + sample);
+}
+
+/* ---- vectors ----------------------------------------------------------------- */
+
+RT_FN rt_v3 rt_v3_make(float x, float y, float z) { rt_v3 v; v.x = x; v.y = y; v.z = z; return v; }
+RT_FN rt_v3 rt_v3_add(rt_v3 a, rt_v3 b) { return rt_v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_FN rt_v3 rt_v3_sub(rt_v3 a, rt_v3 b) { return rt_v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_FN rt_v3 rt_v3_mul(rt_v3 a, rt_v3 b) { return rt_v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_FN rt_v3 rt_v3_scale(rt_v3 a, float s) { return rt_v3_make(a.x * s, a.y * s, a.z * s); }
+RT_FN float rt_v3_dot(rt_v3 a, rt_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+/* common.h:54-60 */
+RT_FN rt_v3 rt_v3_cross(rt_v3 a, rt_v3 b) {
+  return rt_v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+/* codin vec3_normalize: defined here as v * (1 / sqrt(v.v)). */
+RT_FN rt_v3 rt_v3_normalize(rt_v3 v) {
+  float inv = 1.0f / rt_sqrtf(rt_v3_dot(v, v));
+  return rt_v3_scale(v, inv);
+}
+
+/* lerp_f32 of driver.c:283-285; codin vec3_lerp is defined component-wise the same. */
+RT_FN float rt_lerpf(float x, float y, float t) { return x * (1.0f - t) + y * t; }
+RT_FN rt_v3 rt_v3_lerp(rt_v3 a, rt_v3 b, float t) {
+  return rt_v3_make(rt_lerpf(a.x, b.x, t), rt_lerpf(a.y, b.y, t), rt_lerpf(a.z, b.z, t));
+}
+
+/* codin vec3_reflect(v, n) = v - 2 (v.n) n (convention checked against
+ * output.png by the survey probe). */
+RT_FN rt_v3 rt_v3_reflect(rt_v3 v, rt_v3 n) {
+  return rt_v3_sub(v, rt_v3_scale(n, 2.0f * rt_v3_dot(v, n)));
+}
+
+/* ---- elementary functions ---------------------------------------------------- */
+
+/* natural log, x > 0, normal numbers */
+RT_FN float rt_logf(float x) {
+  uint32_t ix = rt_f2u(x);
+  int      e  = (int)(ix >> 23) - 126;
+  float    m  = rt_u2f((ix & 0x007fffffu) | 0x3f000000u);   /* [0.5, 1) */
+  if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+  float z = m * m;
+  float y = 7.0376836292E-2f;
+  y = y * m + -1.1514610310E-1f;
+  y = y * m +  1.1676998740E-1f;
+  y = y * m + -1.2420140846E-1f;
+  y = y * m +  1.4249322787E-1f;
+  y = y * m + -1.6668057665E-1f;
+  y = y * m +  2.0000714765E-1f;
+  y = y * m + -2.4999993993E-1f;
+  y = y * m +  3.3333331174E-1f;
+  y = y * m * z;
+  float fe = (float)e;
+  y = y + -2.12194440e-4f * fe;
+  y = y + -0.5f * z;
+  float r = m + y;
+  r = r + 0.693359375f * fe;
+  return r;
+}
+
+/* e^x for |x| < 87 */
+RT_FN float rt_expf(float x) {
+  float n = rt_floorf(1.44269504088896341f * x + 0.5f);
+  float r = x - n * 0.693359375f;
+  r = r - n * -2.12194440e-4f;
+  float z = r * r;
+  float p = 1.9875691500E-4f;
+  p = p * r + 1.3981999507E-3f;
+  p = p * r + 8.3334519073E-3f;
+  p = p * r + 4.1665795894E-2f;
+  p = p * r + 1.6666665459E-1f;
+  p = p * r + 5.0000001201E-1f;
+  p = p * z + r + 1.0f;
+  int   in = (int)n;
+  float sc = rt_u2f((uint32_t)(in + 127) << 23);
+  return p * sc;
+}
+
+/* pow_f32(x, y) for the path's uses: x >= 0 (common.h:84-91).  x <= 0 -> 0. */
+RT_FN float rt_powf(float x, float y) {
+  if (!(x > 0.0f)) return 0.0f;
+  float t = y * rt_logf(x);
+  t = rt_clampf(t, -87.0f, 87.0f);
+  return rt_expf(t);
+}
+
+/* sin and cos of x, 0 <= x <= ~8 (angles are rand*2pi, driver.c:119,238) */
+RT_FN void rt_sincosf(float x, float *s, float *c) {
+  int q = (int)(x * 1.27323954473516f);       /* x * 4/pi, truncated */
+  q += q & 1;
+  float y = (float)q;
+  float r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+  float z = r * r;
+  float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * r + r;
+  float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
+             - 0.5f * z + 1.0f;
+  int k = (q >> 1) & 3;                        /* x = k*pi/2 + r */
+  float ss = (k & 1) ? pc : ps;
+  float cc = (k & 1) ? ps : pc;
+  if (k == 2 || k == 3) ss = -ss;
+  if (k == 1 || k == 2) cc = -cc;
+  *s = ss;
+  *c = cc;
+}
+
+RT_FN float rt_atanf_pos(float a) {            /* a >= 0 */
+  float yb = 0.0f;
+  if (a > 2.414213562373095f) { yb = 1.5707963267948966192f; a = -(1.0f / a); }
+  else if (a > 0.4142135623730950f) { yb = 0.7853981633974483096f; a = (a - 1.0f) / (a + 1.0f); }
+  float z = a * a;
+  float p = ((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f;
+  return yb + (p * z * a + a);
+}
+
+RT_FN float rt_atan2f(float y, float x) {
+  if (x == 0.0f) {
+    if (y > 0.0f) return 1.5707963267948966192f;
+    if (y < 0.0f) return -1.5707963267948966192f;
+    return 0.0f;
+  }
+  if (y == 0.0f) return x < 0.0f ? RT_PI : 0.0f;
+  float q = y / x;
+  float a = rt_atanf_pos(rt_absf(q));
+  if (q < 0.0f) a = -a;
+  float w = 0.0f;
+  if (x < 0.0f) w = (y < 0.0f) ? -RT_PI : RT_PI;
+  return w + a;
+}
+
+/* asin on [-1, 1]; arguments outside are clamped (the reference's
+ * asin_f32(dir.y), driver.c:100, is NaN when |dir.y| > 1 by rounding). */
+RT_FN float rt_asinf(float x) {
+  float a = rt_absf(x);
+  if (a > 1.0f) a = 1.0f;
+  int   big = a > 0.5f;
+  float z, w;
+  if (big) { z = 0.5f * (1.0f - a); w = rt_sqrtf(z); } else { w = a; z = a * a; }
+  float p = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z + 7.4953002686E-2f) * z
+             + 1.6666752422E-1f) * z * w + w;
+  if (big) p = 1.5707963267948966192f - (p + p);
+  return x < 0.0f ? -p : p;
+}
+
+/* ---- colour (common.h:82-92) -------------------------------------------------- */
+
+/* NOTE: no linear toe segment, exactly like the reference. */
+RT_FN float rt_srgb_to_linear1(float x) { return rt_powf((x + 0.055f) / 1.055f, 2.4f); }
+
+RT_FN rt_v3 rt_srgb_to_linear(rt_v3 c) {
+  return rt_v3_make(rt_srgb_to_linear1(c.x), rt_srgb_to_linear1(c.y), rt_srgb_to_linear1(c.z));
+}
+
+RT_FN float rt_linear_to_srgb(float c) {
+  return (c <= 0.0031308f) ? (12.92f * c) : (1.055f * rt_powf(c, 1.0f / 2.4f) - 0.055f);
+}
+
+/* ---- primary-ray jitter (raytracer.c:584-594) ---------------------------------- */
+
+RT_FN float rt_hash12(float px, float py) {
+  float p3x = rt_fractf(px * 0.1031f);
+  float p3y = rt_fractf(py * 0.1031f);
+  float p3z = rt_fractf(px * 0.1031f);
+  float d = p3x * (p3y + 33.33f) + p3y * (p3z + 33.33f) + p3z * (p3x + 33.33f);
+  return rt_fractf((p3x + p3y + d * 2.0f) * (p3z + d));
+}
+
+/* ---- exact radiance accumulation ------------------------------------------------
+ * Per-sample radiance is summed per pixel in 64-bit fixed point (32 fractional
+ * bits) so that the sum is independent of the order in which samples finish --
+ * the GPU schedules paths dynamically, the oracle walks them in order, and both
+ * get the same integer.  The reference sums in fp32 in sample order
+ * (raytracer.c:695); the oracle can also do that (ORACLE_ACCUM_F32) and tests
+ * bound the difference.  Negative and NaN samples count as 0, samples above
+ * 2^20 are clamped (a pixel saturates at 1.0 long before). */
+#define RT_ACCUM_FRAC_BITS 32
+#define RT_ACCUM_MAX       1048576.0f
+
+RT_FN uint64_t rt_accum_quantize(float c) {
+  float v = (c > 0.0f) ? c : 0.0f;
+  v = (v > RT_ACCUM_MAX) ? RT_ACCUM_MAX : v;
+  return (uint64_t)((double)v * 4294967296.0);
+}
+
+/* sum of `samples` quantised values -> mean radiance, rounded once */
+RT_FN float rt_accum_resolve(uint64_t sum, uint32_t samples) {
+  double mean = (double)sum / ((double)samples * 4294967296.0);
+  return (float)mean;
+}
+
+/* average -> clamp -> sRGB -> u8, raytracer.c:700-716 */
+RT_FN uint8_t rt_encode_u8(float linear) {
+  float c = rt_clampf(linear, 0.0f, 1.0f);
+  c = rt_linear_to_srgb(c);
+  c = c * 255.999f;
+  return (uint8_t)c;
+}
+
+#endif /* RT_MATH_H */

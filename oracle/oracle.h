@@ -1,0 +1,95 @@
+/* oracle.h -- CPU restatement of the reference render path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load liboracle.so; nothing under raytracing_c_amd/ links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
+ * this path and cannot be compiled here (every file includes the absent,
+ * unversioned third-party library "codin": common.h:3-4, raytracer.c:3-7,
+ * scene.c:1-6, driver.c:1-8).  The oracle is therefore a by-hand restatement,
+ * function by function, of common.h:13-92, raytracer.c:15-32,84-230,443-720 and
+ * driver.c:49-104,118-418, with these documented deviations:
+ *   D1 per-path RNG seeding rt_path_seed() instead of wall clock per thread;
+ *   D2 exact 1/sqrt instead of _mm256_rsqrt_ps for primary directions;
+ *   D3 depth-0 BVH tests leaf group 0 instead of reading nodes[0];
+ *   D4 asin argument clamped to [-1,1] in the background lookup;
+ *   D5 no FMA contraction anywhere; libm replaced by include/rt_math.h;
+ *   D6 default accumulation is order-free 32.32 fixed point (rt_math.h);
+ *      ORACLE_ACCUM_F32 reproduces the reference's fp32 running sum.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "../include/rt_raytracer.h"
+#include "../include/rt_materials.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  u64 paths;          /* camera paths started                                  */
+  u64 rays;           /* ray_scene_hit calls (raytracer.c:514)                 */
+  u64 node_visits;    /* ray_aabbs_hit_8 calls (raytracer.c:452)               */
+  u64 leaf_visits;    /* ray_triangles_hit_8 calls (raytracer.c:476)           */
+  u64 shades;         /* shader.proc calls (raytracer.c:535)                   */
+  u64 backgrounds;    /* background.proc calls (raytracer.c:554)               */
+  u64 textured;       /* shades whose material has at least one texture        */
+} Oracle_Counters;
+
+enum { ORACLE_ACCUM_FIXED = 0, ORACLE_ACCUM_F32 = 1 };
+
+typedef struct {
+  /* Addresses that identify the built-in materials inside the Scene (the
+   * product's exported tokens, or the oracle's own functions).  A shader.proc
+   * that matches none of them is CALLED, as the reference would. */
+  Shader_Proc     disney_proc;
+  Shader_Proc     debug_proc;
+  Background_Proc background_proc;
+  u32             seed;
+  i32             accum_mode;      /* ORACLE_ACCUM_*                            */
+  i32             n_threads;       /* >= 1                                      */
+  /* pixel window rendered: [x0,x1) x [y0,y1); zeros = whole image             */
+  i32             x0, y0, x1, y1;
+  /* only samples [sample0, sample0+sample_count) of each pixel are traced;
+   * sample_count == 0 = all.  `samples` still names the pixel's total for
+   * the RNG stream and the final mean.                                        */
+  i32             sample0, sample_count;
+} Oracle_Config;
+
+/* Renders ctx-like arguments with the reference's semantics.
+ *   image   : u8 output (may be NULL), written as raytracer.c:714-716
+ *   linear  : optional W*H*3 f32, mean radiance before clamp/sRGB
+ *   accum   : optional W*H*3 u64 fixed-point sums (ORACLE_ACCUM_FIXED only)
+ * Returns 0, or -1 on invalid arguments. */
+int oracle_render(Scene const *scene, Image const *image, isize samples, isize max_bounces,
+                  Oracle_Config const *config, f32 *linear, u64 *accum, Oracle_Counters *counters);
+
+/* Traces one camera path and returns its radiance (raytracer.c:505-558 +
+ * primary ray of :641-694) */
+void oracle_trace_path(Scene const *scene, Oracle_Config const *config, i32 width, i32 height,
+                       i32 x, i32 y, i32 sample, i32 samples, i32 max_bounces, f32 rgb[3]);
+
+/* ---- unit-level entry points for known-answer tests ---------------------- */
+void oracle_rand_u32_seq(u32 state, i32 n, u32 *out);                        /* common.h:15-20 */
+void oracle_rand_f32_seq(u32 state, i32 n, f32 *out);                        /* common.h:22-24 */
+f32  oracle_hash12(f32 px, f32 py);                                          /* raytracer.c:584-594 */
+void oracle_ray_aabbs_hit_8(Ray const *ray, f32 t_min, f32 t_max, BVH_Node const *node, f32 *distances); /* raytracer.c:190-230 */
+bool oracle_ray_triangles_hit_8(Ray const *ray, Triangles const *tris, isize offset, Hit *hit, i32 *lane); /* raytracer.c:84-188 */
+void oracle_ray_scene_hit(Ray const *ray, Scene const *scene, Hit *hit, i32 *triangle);                     /* raytracer.c:443-503 */
+void oracle_sample_texture_bilinear(Image const *texture, f32 u, f32 v, f32 rgb[3]);                        /* driver.c:49-93 */
+void oracle_sample_background(Image const *image, f32 const dir[3], f32 rgb[3]);                            /* driver.c:95-104 */
+/* driver.c:287-348: returns brdf rgba, writes out_dir; *state is the RNG state */
+void oracle_sample_disney_brdf(f32 roughness, f32 metalness, f32 sheen, f32 sheen_tint, f32 aniso2,
+                               f32 const base_color[3], f32 const in_dir[3], u32 *state, f32 out_dir[3], f32 brdf[4]);
+/* driver.c:350-409 on explicit state */
+void oracle_disney_shade(PBR_Shader_Data const *data, Shader_Input const *in, u32 *state, Shader_Output *out);
+/* rt_math.h wrappers: op 0 log,1 exp,2 pow(x,y),3 sin,4 cos,5 atan2(x=y,y=x),6 asin,7 srgb_to_linear,8 linear_to_srgb,9 sqrt, 10 1/x */
+void oracle_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
+u8   oracle_encode_u8(f32 linear);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ORACLE_H */

@@ -1,0 +1,745 @@
+// rt_api.cpp -- host side of librt_hip.so: the reference's render entry points
+// (raytracer.h:51-56) and the device-control calls of include/rt_hip.h.
+//
+// Nothing in this file computes a pixel on the CPU: every entry point either
+// drives the gfx950 kernels of rt_kernels.hip or fails with rt_last_error().
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_device.h"
+
+// launchers in rt_kernels.hip
+extern "C" {
+int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, hipStream_t stream);
+int rt_launch_resolve(int width, int height, int samples, int chunks_x, int rank, int world, int n_local_chunks,
+                      const unsigned long long *accum, uint8_t *tiles, uint8_t *image, float *linear,
+                      hipStream_t stream);
+int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, int world, int max_local,
+                     const uint8_t *all_tiles, uint8_t *image, hipStream_t stream);
+int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream);
+int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
+                         hipStream_t stream);
+int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
+}
+
+// ---------------------------------------------------------------------------------
+// errors
+
+static std::mutex g_err_mutex;
+static char       g_err[1024] = "";
+
+static int rt_fail(const char *fmt, ...) {
+  std::lock_guard<std::mutex> lock(g_err_mutex);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "rt_hip: %s\n", g_err);
+  return -1;
+}
+
+extern "C" char const *rt_last_error(void) { return g_err; }
+extern "C" void rt_clear_error(void) {
+  std::lock_guard<std::mutex> lock(g_err_mutex);
+  g_err[0] = 0;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return rt_fail("%s failed: %s", #expr, hipGetErrorString(e_));      \
+  } while (0)
+
+#define HIP_TRY_NULL(expr)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) { rt_fail("%s failed: %s", #expr, hipGetErrorString(e_)); return nullptr; } \
+  } while (0)
+
+// ---------------------------------------------------------------------------------
+// process state
+
+static std::mutex g_mutex;          // serialises frames and the scene cache
+static int        g_device = 0;
+static bool       g_device_ready = false;
+static int        g_num_cus = 0;
+static u32        g_seed = 0x1234ABCDu;
+
+struct Workspace {
+  unsigned long long *accum = nullptr;
+  size_t              accum_elems = 0;
+  unsigned long long *counters = nullptr;   // RT_N_COUNTERS
+  uint32_t           *work_head = nullptr;
+  uint8_t            *image = nullptr;
+  float              *linear = nullptr;
+  size_t              image_pixels = 0;
+  hipEvent_t          ev0 = nullptr, ev1 = nullptr;
+  bool                timed = false;
+};
+static Workspace g_ws;
+
+static int ensure_device() {
+  if (g_device_ready) return 0;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    return rt_fail("no HIP device available (%s); the render path has no CPU fallback",
+                   e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  if (g_device >= count) return rt_fail("device %d requested but only %d present", g_device, count);
+  HIP_TRY(hipSetDevice(g_device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  g_num_cus = prop.multiProcessorCount;
+  HIP_TRY(hipMalloc(&g_ws.counters, RT_N_COUNTERS * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&g_ws.work_head, 64));
+  HIP_TRY(hipEventCreate(&g_ws.ev0));
+  HIP_TRY(hipEventCreate(&g_ws.ev1));
+  g_device_ready = true;
+  return 0;
+}
+
+extern "C" int rt_init(int device) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (g_device_ready && device != g_device) return rt_fail("rt_init: device already initialised as %d", g_device);
+  g_device = device;
+  return ensure_device();
+}
+
+extern "C" void rt_set_seed(u32 seed) { g_seed = seed; }
+extern "C" u32  rt_get_seed(void) { return g_seed; }
+
+// ---------------------------------------------------------------------------------
+// material tokens (rt_materials.h): recognised by address, not callable
+
+extern "C" void disney_shader_proc(rawptr, Shader_Input const *, Shader_Output *output) {
+  rt_fail("disney_shader_proc is a device material token and cannot be called on the host");
+  if (output) output->terminate = true;
+}
+
+extern "C" void debug_shader_proc(rawptr, Shader_Input const *, Shader_Output *output) {
+  rt_fail("debug_shader_proc is a device material token and cannot be called on the host");
+  if (output) output->terminate = true;
+}
+
+extern "C" Color3 sample_background(Image const *, Vec3) {
+  rt_fail("sample_background is a device background token and cannot be called on the host");
+  Color3 c;
+  c.x = c.y = c.z = 0.0f;
+  return c;
+}
+
+// ---------------------------------------------------------------------------------
+// scene residency
+
+struct RT_Device_Scene {
+  float       *nodes = nullptr;
+  float       *leaves = nullptr;
+  float       *tris = nullptr;
+  float       *mats = nullptr;
+  RT_DTexture *textures = nullptr;
+  uint32_t    *texels = nullptr;
+  int32_t      depth = 0, last_row_offset = 0, bg_texture = -1, n_nodes = 0;
+  int32_t      n_triangles = 0, n_materials = 0, n_textures = 0;
+  int64_t      bytes = 0;
+  // fingerprint of the host scene this was built from
+  const void  *fp_nodes = nullptr, *fp_tris = nullptr, *fp_bg = nullptr;
+  int64_t      fp_len = 0, fp_depth = 0;
+};
+
+static std::unordered_map<const Scene *, RT_Device_Scene *> g_scene_cache;
+
+static void free_device_scene(RT_Device_Scene *d) {
+  if (!d) return;
+  (void)hipFree(d->nodes);
+  (void)hipFree(d->leaves);
+  (void)hipFree(d->tris);
+  (void)hipFree(d->mats);
+  (void)hipFree(d->textures);
+  (void)hipFree(d->texels);
+  delete d;
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src, int64_t *bytes) {
+  size_t n = src.size() * sizeof(T);
+  if (n == 0) n = 16;
+  HIP_TRY(hipMalloc((void **)dst, n));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  *bytes += (int64_t)n;
+  return 0;
+}
+
+static int texture_index(Image const *img, std::unordered_map<const Image *, int> &map, std::vector<RT_DTexture> &descs,
+                         std::vector<uint32_t> &texels) {
+  if (!img) return -1;
+  auto it = map.find(img);
+  if (it != map.end()) return it->second;
+  if (img->components < 3 || img->width <= 0 || img->height <= 0 || !img->pixels.data || img->stride < img->width) {
+    return -2;
+  }
+  RT_DTexture t;
+  t.offset = (uint32_t)texels.size();
+  t.width = (int32_t)img->width;
+  t.height = (int32_t)img->height;
+  t.stride = (int32_t)img->width;
+  size_t base = texels.size();
+  texels.resize(base + (size_t)img->width * img->height);
+  for (isize y = 0; y < img->height; y++) {
+    const byte *row = img->pixels.data + img->components * (img->stride * y);
+    uint32_t   *dst = texels.data() + base + (size_t)y * img->width;
+    for (isize x = 0; x < img->width; x++) {
+      const byte *p = row + img->components * x;
+      dst[x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
+    }
+  }
+  int idx = (int)descs.size();
+  descs.push_back(t);
+  map[img] = idx;
+  return idx;
+}
+
+static float int_bits(int32_t i) {
+  float f;
+  memcpy(&f, &i, 4);
+  return f;
+}
+
+static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
+  if (ensure_device() != 0) return nullptr;
+  if (!scene) { rt_fail("rt_scene_upload: scene is NULL"); return nullptr; }
+  const Triangles &T = scene->triangles;
+  if (T.len <= 0 || T.len % 8 != 0 || !T.x[0] || !T.aos) {
+    rt_fail("rt_scene_upload: triangle block is empty or not a multiple of 8 (len=%d)", (int)T.len);
+    return nullptr;
+  }
+  if (scene->bvh.depth < 0 || scene->bvh.depth > RT_MAX_DEPTH) {
+    rt_fail("rt_scene_upload: bvh.depth %ld outside [0, %d]", (long)scene->bvh.depth, RT_MAX_DEPTH);
+    return nullptr;
+  }
+  if (scene->bvh.depth > 0) {
+    if (scene->bvh.nodes.len < bvh_n_internal_nodes(scene->bvh.depth) || !scene->bvh.nodes.data) {
+      rt_fail("rt_scene_upload: %ld nodes for depth %ld", (long)scene->bvh.nodes.len, (long)scene->bvh.depth);
+      return nullptr;
+    }
+    if ((isize)T.len < bvh_n_leaf_nodes(scene->bvh.depth) * 8) {
+      rt_fail("rt_scene_upload: %d triangle slots for depth %ld", (int)T.len, (long)scene->bvh.depth);
+      return nullptr;
+    }
+  }
+  if (scene->background.proc != (Background_Proc)sample_background || !scene->background.data) {
+    rt_fail("rt_scene_upload: background.proc is not the exported sample_background token "
+            "(host callbacks cannot run on the GPU)");
+    return nullptr;
+  }
+
+  std::unordered_map<const Image *, int> tex_map;
+  std::vector<RT_DTexture>               descs;
+  std::vector<uint32_t>                  texels;
+  std::unordered_map<uint64_t, int>      mat_map;     // (data ptr, kind) -> id
+  std::vector<float>                     mats;
+
+  // triangles + materials
+  const int n = T.len;
+  std::vector<float> tris((size_t)n * 28, 0.0f);
+  for (int i = 0; i < n; i++) {
+    const Triangle_AOS &a = T.aos[i];
+    int mat = 0;
+    if (a.shader.proc == nullptr) {
+      mat = -1;   // unpopulated slot: never hit (all-zero triangle)
+    } else {
+      int kind;
+      if (a.shader.proc == disney_shader_proc) kind = RT_MAT_DISNEY;
+      else if (a.shader.proc == debug_shader_proc) kind = RT_MAT_DEBUG;
+      else {
+        rt_fail("rt_scene_upload: triangle %d uses a shader proc that is not an exported device material "
+                "(disney_shader_proc / debug_shader_proc)", i);
+        return nullptr;
+      }
+      if (!a.shader.data) { rt_fail("rt_scene_upload: triangle %d has shader.data == NULL", i); return nullptr; }
+      uint64_t key = (uint64_t)(uintptr_t)a.shader.data * 2u + (uint64_t)kind;
+      auto it = mat_map.find(key);
+      if (it != mat_map.end()) {
+        mat = it->second;
+      } else {
+        const PBR_Shader_Data *d = (const PBR_Shader_Data *)a.shader.data;
+        int ta = texture_index(d->texture_albedo, tex_map, descs, texels);
+        int tn = texture_index(d->texture_normal, tex_map, descs, texels);
+        int tm = texture_index(d->texture_metal_roughness, tex_map, descs, texels);
+        int te = texture_index(d->texture_emission, tex_map, descs, texels);
+        if (ta == -2 || tn == -2 || tm == -2 || te == -2) {
+          rt_fail("rt_scene_upload: material of triangle %d references an unusable Image (need u8, >=3 components)", i);
+          return nullptr;
+        }
+        mat = (int)(mats.size() / 20);
+        float m[20] = {d->base_color.x, d->base_color.y, d->base_color.z, d->roughness,
+                       d->emission.x, d->emission.y, d->emission.z, d->metalness,
+                       d->normal_map_strength, d->sheen, d->sheen_tint, d->anisotropic_strength,
+                       int_bits(ta), int_bits(tn), int_bits(tm), int_bits(te),
+                       int_bits(kind), 0.0f, 0.0f, 0.0f};
+        mats.insert(mats.end(), m, m + 20);
+        mat_map[key] = mat;
+      }
+    }
+    float *r = &tris[(size_t)i * 28];
+    r[0] = a.normal.x;    r[1] = a.normal.y;    r[2] = a.normal.z;    r[3] = int_bits(mat < 0 ? 0 : mat);
+    r[4] = a.normal_a.x;  r[5] = a.normal_a.y;  r[6] = a.normal_a.z;  r[7] = a.tex_coords_a.x;
+    r[8] = a.normal_b.x;  r[9] = a.normal_b.y;  r[10] = a.normal_b.z; r[11] = a.tex_coords_a.y;
+    r[12] = a.normal_c.x; r[13] = a.normal_c.y; r[14] = a.normal_c.z; r[15] = a.tex_coords_b.x;
+    r[16] = a.tangent.x;  r[17] = a.tangent.y;  r[18] = a.tangent.z;  r[19] = a.tex_coords_b.y;
+    r[20] = a.bitangent.x; r[21] = a.bitangent.y; r[22] = a.bitangent.z; r[23] = a.tex_coords_c.x;
+    r[24] = a.tex_coords_c.y;
+  }
+  if (mats.empty()) mats.resize(20, 0.0f);
+
+  // leaf tiles: 9 rows x 8 per group
+  const int n_groups = n / 8;
+  std::vector<float> leaves((size_t)n_groups * 72);
+  for (int g = 0; g < n_groups; g++) {
+    float *l = &leaves[(size_t)g * 72];
+    for (int k = 0; k < 3; k++) {
+      memcpy(l + (0 + k) * 8, T.x[k] + g * 8, 32);
+      memcpy(l + (3 + k) * 8, T.y[k] + g * 8, 32);
+      memcpy(l + (6 + k) * 8, T.z[k] + g * 8, 32);
+    }
+  }
+
+  std::vector<float> nodes;
+  if (scene->bvh.depth > 0) {
+    const float *src = (const float *)scene->bvh.nodes.data;
+    nodes.assign(src, src + (size_t)scene->bvh.nodes.len * 48);
+  }
+
+  int bg = texture_index((Image const *)scene->background.data, tex_map, descs, texels);
+  if (bg < 0) { rt_fail("rt_scene_upload: background Image is unusable (need u8, >=3 components)"); return nullptr; }
+
+  RT_Device_Scene *d = new RT_Device_Scene();
+  if (upload(&d->nodes, nodes, &d->bytes) || upload(&d->leaves, leaves, &d->bytes) ||
+      upload(&d->tris, tris, &d->bytes) || upload(&d->mats, mats, &d->bytes) ||
+      upload(&d->textures, descs, &d->bytes) || upload(&d->texels, texels, &d->bytes)) {
+    free_device_scene(d);
+    return nullptr;
+  }
+  d->depth = (int32_t)scene->bvh.depth;
+  d->last_row_offset = (int32_t)scene->bvh.last_row_offset;
+  d->bg_texture = bg;
+  d->n_nodes = (int32_t)scene->bvh.nodes.len;
+  d->n_triangles = n;
+  d->n_materials = (int32_t)(mats.size() / 20);
+  d->n_textures = (int32_t)descs.size();
+  d->fp_nodes = scene->bvh.nodes.data;
+  d->fp_tris = T.x[0];
+  d->fp_bg = scene->background.data;
+  d->fp_len = T.len;
+  d->fp_depth = scene->bvh.depth;
+  return d;
+}
+
+// Camera of an explicitly uploaded scene: captured at upload, replaced by
+// rt_set_camera().  (render_thread_proc reads the host Scene's camera per frame.)
+static std::unordered_map<RT_Device_Scene *, Camera> g_cameras;
+
+extern "C" RT_Device_Scene *rt_scene_upload(Scene const *scene) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  RT_Device_Scene *d = upload_scene_locked(scene);
+  if (d) g_cameras[d] = scene->camera;
+  return d;
+}
+
+extern "C" void rt_scene_release(RT_Device_Scene *dscene) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  for (auto it = g_scene_cache.begin(); it != g_scene_cache.end(); ++it) {
+    if (it->second == dscene) { g_scene_cache.erase(it); break; }
+  }
+  g_cameras.erase(dscene);
+  free_device_scene(dscene);
+}
+
+extern "C" void rt_scene_invalidate(Scene const *scene) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  auto it = g_scene_cache.find(scene);
+  if (it != g_scene_cache.end()) {
+    free_device_scene(it->second);
+    g_scene_cache.erase(it);
+  }
+}
+
+extern "C" i64 rt_scene_device_bytes(RT_Device_Scene const *dscene) { return dscene ? dscene->bytes : 0; }
+
+static RT_Device_Scene *cached_scene_locked(Scene const *scene) {
+  auto it = g_scene_cache.find(scene);
+  if (it != g_scene_cache.end()) {
+    RT_Device_Scene *d = it->second;
+    if (d->fp_nodes == scene->bvh.nodes.data && d->fp_tris == scene->triangles.x[0] &&
+        d->fp_bg == scene->background.data && d->fp_len == scene->triangles.len && d->fp_depth == scene->bvh.depth) {
+      return d;
+    }
+    free_device_scene(d);
+    g_scene_cache.erase(it);
+  }
+  RT_Device_Scene *d = upload_scene_locked(scene);
+  if (d) g_scene_cache[scene] = d;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------
+// rendering
+
+extern "C" i32 rt_chunk_count(i32 width, i32 height) {
+  if (width <= 0 || height <= 0) return 0;
+  return ((width + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE) * ((height + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE);
+}
+
+extern "C" i32 rt_local_chunk_count(i32 width, i32 height, i32 rank, i32 world) {
+  i32 n = rt_chunk_count(width, height);
+  if (world <= 0 || rank < 0 || rank >= world) return 0;
+  return (n - rank + world - 1) / world;
+}
+
+static int check_params(RT_Render_Params const *p) {
+  if (!p) return rt_fail("render params are NULL");
+  if (p->width <= 0 || p->height <= 0) return rt_fail("image size %dx%d is invalid", p->width, p->height);
+  if ((int64_t)p->width * p->height > (int64_t)1 << 28) return rt_fail("image %dx%d is too large", p->width, p->height);
+  if (p->samples <= 0) return rt_fail("samples must be positive (got %d)", p->samples);
+  if (p->max_bounces < 0) return rt_fail("max_bounces must be >= 0 (got %d)", p->max_bounces);
+  if (p->world <= 0 || p->rank < 0 || p->rank >= p->world) return rt_fail("rank %d / world %d is invalid", p->rank, p->world);
+  return 0;
+}
+
+static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p,
+                        void *d_accum) {
+  memset(K, 0, sizeof *K);
+  K->nodes = d->nodes;
+  K->leaves = d->leaves;
+  K->tris = d->tris;
+  K->mats = d->mats;
+  K->textures = d->textures;
+  K->texels = d->texels;
+  K->depth = d->depth;
+  K->last_row_offset = d->last_row_offset;
+  K->bg_texture = d->bg_texture;
+  K->n_nodes = d->n_nodes;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) K->cam[i][j] = cam->view_matrix.rows[i][j];
+  K->focal_length = cam->focal_length;
+  K->width = p->width;
+  K->height = p->height;
+  K->samples = p->samples;
+  K->max_bounces = p->max_bounces;
+  K->seed = p->seed;
+  K->chunks_x = (p->width + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE;
+  K->n_chunks = rt_chunk_count(p->width, p->height);
+  K->rank = p->rank;
+  K->world = p->world;
+  K->n_local_chunks = rt_local_chunk_count(p->width, p->height, p->rank, p->world);
+  int slab = p->slab > 0 ? p->slab : 64;
+  int shift = 0;
+  while ((1 << shift) < slab && (1 << shift) < p->samples) shift++;
+  K->slab_shift = shift;
+  K->n_slabs = (p->samples + (1 << shift) - 1) >> shift;
+  int64_t n_work = (int64_t)K->n_local_chunks * 16 * K->n_slabs;
+  if (n_work > 0x7fffffff) return rt_fail("too many work items (%lld)", (long long)n_work);
+  K->n_work = (int32_t)n_work;
+  K->accum = (unsigned long long *)d_accum;
+  K->counters = g_ws.counters;
+  K->work_head = g_ws.work_head;
+  return 0;
+}
+
+static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p, void *d_accum,
+                                    hipStream_t stream) {
+  if (ensure_device() != 0) return -1;
+  if (check_params(p) != 0) return -1;
+  if (!d || !d_accum) return rt_fail("rt_render_accumulate: NULL scene or accumulation buffer");
+  RT_KParams K;
+  if (fill_kparams(&K, d, cam, p, d_accum) != 0) return -1;
+  HIP_TRY(hipMemsetAsync(g_ws.counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(g_ws.work_head, 0, 64, stream));
+  if (K.n_work == 0) return 0;
+  // persistent grid: enough waves to fill the machine, never more than the work
+  int waves = K.n_work;
+  int blocks = (waves + 3) / 4;
+  int max_blocks = g_num_cus * 4;            // 16 waves per CU
+  if (const char *e = getenv("RT_BLOCKS_PER_CU")) {
+    int v = atoi(e);
+    if (v > 0) max_blocks = g_num_cus * v;
+  }
+  if (blocks > max_blocks) blocks = max_blocks;
+  HIP_TRY(hipEventRecord(g_ws.ev0, stream));
+  int rc = rt_launch_path_kernel(&K, blocks, stream);
+  if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  HIP_TRY(hipEventRecord(g_ws.ev1, stream));
+  g_ws.timed = true;
+  return 0;
+}
+
+extern "C" int rt_set_camera(RT_Device_Scene *dscene, Camera const *camera) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!dscene || !camera) return rt_fail("rt_set_camera: NULL argument");
+  g_cameras[dscene] = *camera;
+  return 0;
+}
+
+extern "C" int rt_render_accumulate(RT_Device_Scene *dscene, RT_Render_Params const *params, void *d_accum,
+                                    void *stream) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  auto it = g_cameras.find(dscene);
+  if (it == g_cameras.end()) return rt_fail("rt_render_accumulate: no camera set for this scene (rt_set_camera)");
+  return render_accumulate_locked(dscene, &it->second, params, d_accum, (hipStream_t)stream);
+}
+
+extern "C" int rt_resolve(RT_Render_Params const *p, void const *d_accum, void *d_tiles, void *d_image,
+                          void *d_linear, void *stream) {
+  if (ensure_device() != 0) return -1;
+  if (check_params(p) != 0) return -1;
+  if (!d_accum) return rt_fail("rt_resolve: NULL accumulation buffer");
+  int chunks_x = (p->width + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE;
+  int n_local = rt_local_chunk_count(p->width, p->height, p->rank, p->world);
+  int rc = rt_launch_resolve(p->width, p->height, p->samples, chunks_x, p->rank, p->world, n_local,
+                             (const unsigned long long *)d_accum, (uint8_t *)d_tiles, (uint8_t *)d_image,
+                             (float *)d_linear, (hipStream_t)stream);
+  if (rc != 0) return rt_fail("resolve kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+extern "C" int rt_untile(i32 width, i32 height, i32 world, void const *d_all_tiles, void *d_image, void *stream) {
+  if (ensure_device() != 0) return -1;
+  if (width <= 0 || height <= 0 || world <= 0 || !d_all_tiles || !d_image) return rt_fail("rt_untile: bad arguments");
+  int chunks_x = (width + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE;
+  int n_chunks = rt_chunk_count(width, height);
+  int max_local = (n_chunks + world - 1) / world;
+  int rc = rt_launch_untile(width, height, chunks_x, n_chunks, world, max_local, (const uint8_t *)d_all_tiles,
+                            (uint8_t *)d_image, (hipStream_t)stream);
+  if (rc != 0) return rt_fail("untile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+static int ensure_frame_buffers(int width, int height) {
+  size_t pixels = (size_t)width * height;
+  if (g_ws.accum_elems < pixels * 3) {
+    (void)hipFree(g_ws.accum);
+    g_ws.accum = nullptr;
+    g_ws.accum_elems = 0;
+    HIP_TRY(hipMalloc(&g_ws.accum, pixels * 3 * sizeof(unsigned long long)));
+    g_ws.accum_elems = pixels * 3;
+  }
+  if (g_ws.image_pixels < pixels) {
+    (void)hipFree(g_ws.image);
+    (void)hipFree(g_ws.linear);
+    g_ws.image = nullptr;
+    g_ws.linear = nullptr;
+    g_ws.image_pixels = 0;
+    HIP_TRY(hipMalloc(&g_ws.image, pixels * 3));
+    HIP_TRY(hipMalloc(&g_ws.linear, pixels * 3 * sizeof(float)));
+    g_ws.image_pixels = pixels;
+  }
+  return 0;
+}
+
+static int render_frame_locked(Scene const *scene, Image const *image, isize samples, isize max_bounces,
+                               f32 *linear, u64 *accum) {
+  if (ensure_device() != 0) return -1;
+  if (!scene || !image) return rt_fail("render: NULL scene or image");
+  if (image->pixels.data && image->components < 3) return rt_fail("render: image needs >= 3 components");
+  if (image->pixels.data && image->stride < image->width) return rt_fail("render: image stride < width");
+  RT_Render_Params p;
+  memset(&p, 0, sizeof p);
+  p.width = (i32)image->width;
+  p.height = (i32)image->height;
+  p.samples = (i32)samples;
+  p.max_bounces = (i32)max_bounces;
+  p.seed = g_seed;
+  p.rank = 0;
+  p.world = 1;
+  if (check_params(&p) != 0) return -1;
+  RT_Device_Scene *d = cached_scene_locked(scene);
+  if (!d) return -1;
+  if (ensure_frame_buffers(p.width, p.height) != 0) return -1;
+
+  size_t pixels = (size_t)p.width * p.height;
+  hipStream_t stream = nullptr;
+  HIP_TRY(hipMemsetAsync(g_ws.accum, 0, pixels * 3 * sizeof(unsigned long long), stream));
+  if (render_accumulate_locked(d, &scene->camera, &p, g_ws.accum, stream) != 0) return -1;
+  if (rt_resolve(&p, g_ws.accum, nullptr, g_ws.image, linear ? g_ws.linear : nullptr, stream) != 0) return -1;
+
+  if (image->pixels.data) {
+    if (image->components == 3 && image->stride == image->width) {
+      HIP_TRY(hipMemcpyAsync(image->pixels.data, g_ws.image, pixels * 3, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    } else {
+      std::vector<uint8_t> tmp(pixels * 3);
+      HIP_TRY(hipMemcpy(tmp.data(), g_ws.image, pixels * 3, hipMemcpyDeviceToHost));
+      for (isize y = 0; y < image->height; y++)
+        for (isize x = 0; x < image->width; x++)
+          for (int c = 0; c < 3; c++)
+            image->pixels.data[image->components * (x + y * image->stride) + c] = tmp[((size_t)y * p.width + x) * 3 + c];
+    }
+  }
+  if (linear) HIP_TRY(hipMemcpy(linear, g_ws.linear, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (accum) HIP_TRY(hipMemcpy(accum, g_ws.accum, pixels * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int rt_render_frame(Scene const *scene, Image const *image, isize samples, isize max_bounces, f32 *linear,
+                               u64 *accum) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  return render_frame_locked(scene, image, samples, max_bounces, linear, accum);
+}
+
+extern "C" int rt_get_counters(RT_Counters *out) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!out) return rt_fail("rt_get_counters: NULL");
+  if (ensure_device() != 0) return -1;
+  unsigned long long c[RT_N_COUNTERS];
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(c, g_ws.counters, sizeof c, hipMemcpyDeviceToHost));
+  out->paths = c[0];
+  out->rays = c[1];
+  out->node_visits = c[2];
+  out->leaf_visits = c[3];
+  out->shades = c[4];
+  out->backgrounds = c[5];
+  out->textured = c[6];
+  return 0;
+}
+
+extern "C" f32 rt_last_kernel_ms(void) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!g_device_ready || !g_ws.timed) return -1.0f;
+  if (hipEventSynchronize(g_ws.ev1) != hipSuccess) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventElapsedTime(&ms, g_ws.ev0, g_ws.ev1) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+// ---------------------------------------------------------------------------------
+// the reference's entry points
+
+extern "C" void render_thread_proc(Rendering_Context *ctx) {
+  if (!ctx) return;
+  i32 c = __atomic_fetch_add(&ctx->_current_chunk, 1, __ATOMIC_SEQ_CST);
+  if (c == 0) {
+    // this entrant owns the frame
+    int rc;
+    {
+      std::lock_guard<std::mutex> lock(g_mutex);
+      rc = render_frame_locked(ctx->scene, &ctx->image, ctx->samples, ctx->max_bounces, nullptr, nullptr);
+    }
+    (void)rc;   // failure text is in rt_last_error(); the context still completes
+    i32 n_chunks = rt_chunk_count((i32)ctx->image.width, (i32)ctx->image.height);
+    __atomic_store_n(&ctx->_current_chunk, n_chunks > 0 ? n_chunks : 1, __ATOMIC_SEQ_CST);
+  }
+  __atomic_fetch_add(&ctx->n_threads, -1, __ATOMIC_SEQ_CST);
+}
+
+extern "C" bool rendering_context_is_finished(Rendering_Context *context) {
+  return __atomic_load_n(&context->n_threads, __ATOMIC_SEQ_CST) == 0;
+}
+
+extern "C" void rendering_context_finish(Rendering_Context *context) {
+  while (__atomic_load_n(&context->n_threads, __ATOMIC_SEQ_CST) > 0) std::this_thread::yield();
+}
+
+extern "C" void lightmap_bake(Image const *, Scene const *, isize) {
+  rt_fail("lightmap_bake is not implemented on the GPU yet (unused by the reference driver; SURVEY.md 8f #4)");
+}
+
+extern "C" int render(Scene *scene, Image *image, isize samples, isize max_bounces) {
+  return rt_render_frame(scene, image, samples, max_bounces, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------
+// unit-level device entry points
+
+extern "C" int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (n <= 0 || !x || !out) return rt_fail("rt_test_math: bad arguments");
+  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  size_t bytes = (size_t)n * sizeof(float);
+  HIP_TRY(hipMalloc(&dx, bytes));
+  HIP_TRY(hipMalloc(&dout, bytes));
+  HIP_TRY(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+  if (y) {
+    HIP_TRY(hipMalloc(&dy, bytes));
+    HIP_TRY(hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
+  }
+  int rc = rt_launch_test_math(op, n, dx, dy, dout, nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  (void)hipFree(dout);
+  if (rc != 0) return rt_fail("rt_test_math failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
+  memset(K, 0, sizeof *K);
+  K->nodes = d->nodes;
+  K->leaves = d->leaves;
+  K->tris = d->tris;
+  K->mats = d->mats;
+  K->textures = d->textures;
+  K->texels = d->texels;
+  K->depth = d->depth;
+  K->last_row_offset = d->last_row_offset;
+  K->bg_texture = d->bg_texture;
+  K->n_nodes = d->n_nodes;
+}
+
+extern "C" int rt_test_trace(RT_Device_Scene *d, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (!d || n <= 0 || !rays || !out_t || !out_tri || !out_uv) return rt_fail("rt_test_trace: bad arguments");
+  RT_KParams K;
+  scene_only_kparams(&K, d);
+  float *dr = nullptr, *dt = nullptr, *duv = nullptr;
+  int   *dtri = nullptr;
+  HIP_TRY(hipMalloc(&dr, (size_t)n * 24));
+  HIP_TRY(hipMalloc(&dt, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dtri, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&duv, (size_t)n * 8));
+  HIP_TRY(hipMemcpy(dr, rays, (size_t)n * 24, hipMemcpyHostToDevice));
+  int rc = rt_launch_test_trace(&K, n, dr, dt, dtri, duv, nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out_t, dt, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (rc == 0) rc = (int)hipMemcpy(out_tri, dtri, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (rc == 0) rc = (int)hipMemcpy(out_uv, duv, (size_t)n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(dr);
+  (void)hipFree(dt);
+  (void)hipFree(dtri);
+  (void)hipFree(duv);
+  if (rc != 0) return rt_fail("rt_test_trace failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+extern "C" int rt_test_texture(RT_Device_Scene *d, i32 tex, i32 n, f32 const *uv, f32 *out_rgb) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (!d || n <= 0 || !uv || !out_rgb) return rt_fail("rt_test_texture: bad arguments");
+  if (tex < 0) tex = d->bg_texture;
+  if (tex >= d->n_textures) return rt_fail("rt_test_texture: texture %d of %d", tex, d->n_textures);
+  RT_KParams K;
+  scene_only_kparams(&K, d);
+  float *duv = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(&duv, (size_t)n * 8));
+  HIP_TRY(hipMalloc(&dout, (size_t)n * 12));
+  HIP_TRY(hipMemcpy(duv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+  int rc = rt_launch_test_texture(&K, tex, n, duv, dout, nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out_rgb, dout, (size_t)n * 12, hipMemcpyDeviceToHost);
+  (void)hipFree(duv);
+  (void)hipFree(dout);
+  if (rc != 0) return rt_fail("rt_test_texture failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}

@@ -1,0 +1,86 @@
+/* rt_device.h -- layout of the flattened scene in HBM and the kernel argument
+ * block.  Shared by rt_api.cpp (host, fills it) and rt_kernels.hip (reads it).
+ *
+ * HBM layout (all read-only during a frame, 16-byte aligned):
+ *   nodes   : BVH_Node as is, 12 float4 per node                 192 B / node
+ *   leaves  : per leaf group g, 9 rows of 8 f32 (x0 x1 x2 y0 y1 y2 z0 z1 z2),
+ *             i.e. the reference's nine SoA arrays (scene.h:53-63) re-tiled so
+ *             one group is 288 contiguous bytes                   288 B / leaf
+ *   tris    : Triangle_AOS without the Shader pair, plus a material id
+ *                                                                 112 B / tri
+ *   mats    : PBR_Shader_Data with texture pointers replaced by indices
+ *                                                                  80 B / mat
+ *   textures: descriptor table + one RGBA8 texel pool
+ */
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+
+#define RT_NODE_F4   12      /* float4 per node           */
+#define RT_LEAF_F4   18      /* float4 per leaf group     */
+#define RT_TRI_F4     7      /* float4 per triangle record*/
+#define RT_MAT_F4     5      /* float4 per material       */
+#define RT_MAX_DEPTH  8      /* perm-stack levels in LDS  */
+
+#define RT_MAT_DISNEY 0
+#define RT_MAT_DEBUG  1
+
+#define RT_TILE      8       /* work item = 8x8 pixel tile x sample slab */
+#define RT_TILE_PIX  64
+
+#define RT_N_COUNTERS 8
+
+/* triangle record, 28 floats:
+ *  [0..2] face normal      [3]  material id (int bits)
+ *  [4..6] normal_a         [7]  uv_a.x
+ *  [8..10] normal_b        [11] uv_a.y
+ *  [12..14] normal_c       [15] uv_b.x
+ *  [16..18] tangent        [19] uv_b.y
+ *  [20..22] bitangent      [23] uv_c.x
+ *  [24] uv_c.y             [25..27] pad
+ */
+
+/* material record, 20 floats:
+ *  [0..2] base_color  [3] roughness
+ *  [4..6] emission    [7] metalness
+ *  [8] normal_map_strength [9] sheen [10] sheen_tint [11] anisotropic_strength
+ *  [12] tex_albedo [13] tex_normal [14] tex_metal_roughness [15] tex_emission (int bits, -1 none)
+ *  [16] kind (int bits)  [17..19] pad
+ */
+
+typedef struct {
+  uint32_t offset;    /* first texel in the pool */
+  int32_t  width, height, stride;
+} RT_DTexture;
+
+typedef struct {
+  /* scene */
+  const float    *nodes;
+  const float    *leaves;
+  const float    *tris;
+  const float    *mats;
+  const RT_DTexture *textures;
+  const uint32_t *texels;      /* RGBA8 */
+  int32_t depth;               /* bvh.depth                */
+  int32_t last_row_offset;     /* bvh.last_row_offset      */
+  int32_t bg_texture;          /* index into textures      */
+  int32_t n_nodes;
+  /* camera: rows 0..2 of view_matrix (rotation | translation), focal length */
+  float cam[3][4];
+  float focal_length;
+  /* frame */
+  int32_t width, height, samples, max_bounces;
+  uint32_t seed;
+  int32_t chunks_x, n_chunks;
+  int32_t rank, world, n_local_chunks;
+  int32_t slab_shift;          /* samples per work item = 1 << slab_shift */
+  int32_t n_slabs;             /* ceil(samples / slab)                    */
+  int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
+  /* outputs */
+  unsigned long long *accum;   /* [height*width*3] 32.32 fixed point      */
+  unsigned long long *counters;/* RT_N_COUNTERS                           */
+  uint32_t *work_head;         /* dequeue counter                         */
+} RT_KParams;
+
+#endif /* RT_DEVICE_H */

@@ -1,0 +1,832 @@
+// rt_kernels.hip -- gfx950 device code of the render hot path.
+//
+// What runs here replaces, on the GPU, the reference's
+//   render_thread_proc   raytracer.c:596-720   (pixel / sample loop)
+//   cast_ray             raytracer.c:505-558   (bounce loop)
+//   ray_bvh_node_hit     raytracer.c:443-483   (near-first 8-ary traversal)
+//   ray_aabbs_hit_8      raytracer.c:190-230   (8-box slab test)
+//   ray_triangles_hit_8  raytracer.c:84-188    (8-triangle Moeller-Trumbore)
+//   disney_shader_proc & friends  driver.c:49-418 (textures, BSDF, background)
+//
+// Design (DESIGN.md has the long form):
+//  * One persistent wave64 per scheduler slot.  A wave dequeues work items
+//    (8x8 pixel tile x slab of samples) from a global head counter and keeps all
+//    64 lanes busy by path regeneration: a lane whose path ended takes the next
+//    (pixel, sample) of the item through a wave ballot / prefix count.
+//  * One ray per lane.  Traversal keeps, per lane and per tree level, one
+//    32-bit word in LDS holding the not-yet-visited children of the node on
+//    that level in near-first order (3 bits each + count).  The entry distance
+//    of a popped child is recomputed from the node (6 floats) only when the
+//    closest hit changed since that node was entered; this reproduces the
+//    reference's visiting order and its `dist < hit.distance` test exactly.
+//  * Radiance is accumulated in 32.32 fixed point (rt_math.h), first in LDS
+//    per tile, then with 64-bit integer atomics in HBM: exact and independent
+//    of scheduling, so images are bit-identical to the CPU oracle.
+//  * All arithmetic goes through include/rt_math.h and is compiled with
+//    -ffp-contract=off: no fused multiply-add that the CPU would not do.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+#include "../../include/rt_math.h"
+
+#define RT_BLOCK_WAVES 4
+#define RT_BLOCK_THREADS (RT_BLOCK_WAVES * 64)
+
+// counters slots
+#define CNT_PATHS 0
+#define CNT_RAYS 1
+#define CNT_NODES 2
+#define CNT_LEAVES 3
+#define CNT_SHADES 4
+#define CNT_BG 5
+#define CNT_TEXTURED 6
+
+struct Ray3 {
+  rt_v3 o, d;
+  float inv_x, inv_y, inv_z;
+};
+
+struct HitRec {
+  float t;
+  int   tri;
+  float u, v;
+};
+
+struct LaneCounters {
+  uint32_t rays, nodes, leaves, shades, bgs, textured, paths;
+};
+
+__device__ __forceinline__ float4 ld4(const float *base, int idx4) {
+  return reinterpret_cast<const float4 *>(base)[idx4];
+}
+
+__device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
+__device__ __forceinline__ int   as_i(float f) { return __float_as_int(f); }
+
+// ---------------------------------------------------------------------------------
+// slab test of one child box, operand order of raytracer.c:209-228
+__device__ __forceinline__ float slab_entry(const Ray3 &r, float mnx, float mny, float mnz,
+                                            float mxx, float mxy, float mxz, float t_max) {
+  float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
+  float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
+  float t0z = (mnz - r.o.z) * r.inv_z, t1z = (mxz - r.o.z) * r.inv_z;
+  float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
+  float bx = rt_max_ps(t0x, t1x), by = rt_max_ps(t0y, t1y), bz = rt_max_ps(t0z, t1z);
+  float t_minv = rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
+  float t_maxv = rt_min_ps(t_max, rt_min_ps(bx, rt_min_ps(by, bz)));
+  return (t_minv >= t_maxv) ? RT_INF : t_minv;
+}
+
+// Entry distance of child j only; the miss test against t_max was already passed
+// when the node was entered, so only t_minv is needed (see header comment).
+__device__ __forceinline__ float slab_entry_child(const RT_KParams &P, const Ray3 &r, int node, int j) {
+  const float *n = P.nodes + (size_t)node * 48 + j;
+  float mnx = n[0], mny = n[8], mnz = n[16], mxx = n[24], mxy = n[32], mxz = n[40];
+  float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
+  float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
+  float t0z = (mnz - r.o.z) * r.inv_z, t1z = (mxz - r.o.z) * r.inv_z;
+  float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
+  return rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
+}
+
+// Tests the 8 children of `node` against the ray with t_max = hit_t and returns
+// the near-first visiting order of the children that can still matter:
+//   bits 0..23  child indices, nearest first (ties: lowest index first)
+//   bits 24..27 how many
+// This is the selection loop of raytracer.c:459-468 done once, as a rank sort.
+__device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t) {
+  const float *nb = P.nodes + (size_t)node * 48;
+  float4 a;
+  float mnx[8], mny[8], mnz[8], mxx[8], mxy[8], mxz[8];
+#define LD8(dst, q)                                                       \
+  a = ld4(nb, (q));     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; \
+  a = ld4(nb, (q) + 1); dst[4] = a.x; dst[5] = a.y; dst[6] = a.z; dst[7] = a.w;
+  LD8(mnx, 0) LD8(mny, 2) LD8(mnz, 4) LD8(mxx, 6) LD8(mxy, 8) LD8(mxz, 10)
+#undef LD8
+
+  float d[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float e = slab_entry(r, mnx[k], mny[k], mnz[k], mxx[k], mxy[k], mxz[k], hit_t);
+    d[k] = (e < hit_t) ? e : RT_INF;       // candidate test of raytracer.c:464
+  }
+
+  int rank[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) rank[k] = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+#pragma unroll
+    for (int k = j + 1; k < 8; k++) {
+      int kb = d[k] < d[j];
+      rank[j] += kb;
+      rank[k] += 1 - kb;
+    }
+  }
+  uint32_t w = 0, cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    bool c = d[j] < RT_INF;
+    w |= c ? ((uint32_t)j << (3 * rank[j])) : 0u;
+    cnt += c ? 1u : 0u;
+  }
+  return w | (cnt << 24);
+}
+
+// 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32)
+__device__ __forceinline__ bool leaf_test(const RT_KParams &P, const Ray3 &r, int g, HitRec &hit) {
+  const float *lb = P.leaves + (size_t)g * 72;
+  float best = RT_INF, bu = 0.0f, bv = 0.0f;
+  int   bi = 0;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    float4 x0 = ld4(lb, 0 + h), x1 = ld4(lb, 2 + h), x2 = ld4(lb, 4 + h);
+    float4 y0 = ld4(lb, 6 + h), y1 = ld4(lb, 8 + h), y2 = ld4(lb, 10 + h);
+    float4 z0 = ld4(lb, 12 + h), z1 = ld4(lb, 14 + h), z2 = ld4(lb, 16 + h);
+    float ax[4] = {x0.x, x0.y, x0.z, x0.w}, bx[4] = {x1.x, x1.y, x1.z, x1.w}, cx[4] = {x2.x, x2.y, x2.z, x2.w};
+    float ay[4] = {y0.x, y0.y, y0.z, y0.w}, by[4] = {y1.x, y1.y, y1.z, y1.w}, cy[4] = {y2.x, y2.y, y2.z, y2.w};
+    float az[4] = {z0.x, z0.y, z0.z, z0.w}, bz[4] = {z1.x, z1.y, z1.z, z1.w}, cz[4] = {z2.x, z2.y, z2.z, z2.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      rt_v3 a = rt_v3_make(ax[k], ay[k], az[k]);
+      rt_v3 edge1 = rt_v3_sub(rt_v3_make(bx[k], by[k], bz[k]), a);
+      rt_v3 edge2 = rt_v3_sub(rt_v3_make(cx[k], cy[k], cz[k]), a);
+      rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
+      float det = rt_v3_dot(edge1, rxe2);
+      float inv_det = 1.0f / det;
+      rt_v3 s = rt_v3_sub(r.o, a);
+      rt_v3 sxe1 = rt_v3_cross(s, edge1);
+      float u = inv_det * rt_v3_dot(s, rxe2);
+      float v = inv_det * rt_v3_dot(r.d, sxe1);
+      float t = inv_det * rt_v3_dot(edge2, sxe1);
+      bool miss = (u < -RT_EPS) || (u > 1.0f + RT_EPS) || (v < -RT_EPS) || (u + v > 1.0f + RT_EPS) || (t < RT_EPS);
+      float dist = miss ? RT_INF : t;
+      dist = (dist > 0.0f) ? dist : RT_INF;          // NaN -> +inf (min_f32x8)
+      if (dist < best) { best = dist; bi = h * 4 + k; bu = u; bv = v; }   // lowest lane wins ties
+    }
+  }
+  if (best < hit.t) {
+    hit.t = best;
+    hit.tri = g * 8 + bi;
+    hit.u = bu;
+    hit.v = bv;
+    return true;
+  }
+  return false;
+}
+
+// Closest hit along r (raytracer.c:497-503 -> :443-483).  perm = this wave's
+// LDS perm-stack, indexed [level*64 + lane].
+__device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, HitRec &hit,
+                                          uint32_t *perm, int lane, LaneCounters &cn) {
+  hit.t = RT_INF;
+  hit.tri = -1;
+  hit.u = 0.0f;
+  hit.v = 0.0f;
+  cn.rays += 1;
+  if (P.depth <= 0) {          // one leaf group, no nodes (rt_scene.h, depth-0 rule)
+    cn.leaves += 1;
+    leaf_test(P, r, 0, hit);
+    return;
+  }
+  const int leaf_level = P.depth - 1;
+  int      level = 0, node = 0;
+  uint32_t dirty = 0;
+  cn.nodes += 1;
+  uint32_t cur = node_enter(P, r, 0, hit.t);
+
+  while (level >= 0) {
+    uint32_t cnt = cur >> 24;
+    bool do_leaf = false, do_enter = false;
+    int  child = 0;
+    if (cnt == 0) {
+      level -= 1;
+      node = (node - 1) >> 3;
+      if (level >= 0) cur = perm[level * 64 + lane];
+    } else {
+      int j = (int)(cur & 7u);
+      cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
+      bool go = true;
+      if ((dirty >> level) & 1u) {
+        float dj = slab_entry_child(P, r, node, j);
+        if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
+      }
+      if (go) {
+        child = 8 * node + 1 + j;
+        do_leaf = (level == leaf_level);
+        do_enter = !do_leaf;
+      }
+    }
+    if (do_leaf) {
+      cn.leaves += 1;
+      if (leaf_test(P, r, child - P.last_row_offset, hit)) dirty = 0xFFFFFFFFu;
+    }
+    if (do_enter) {
+      perm[level * 64 + lane] = cur;
+      node = child;
+      level += 1;
+      cn.nodes += 1;
+      cur = node_enter(P, r, node, hit.t);
+      dirty &= ~(1u << level);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// textures (driver.c:49-93); texels are RGBA8, alpha unused
+__device__ __forceinline__ rt_v3 texel_rgb(uint32_t t) {
+  return rt_v3_make((float)(int)(t & 0xFFu) / 255.999f, (float)(int)((t >> 8) & 0xFFu) / 255.999f,
+                    (float)(int)((t >> 16) & 0xFFu) / 255.999f);
+}
+
+__device__ __forceinline__ rt_v3 tex_bilinear(const RT_KParams &P, int tex, float tx, float ty) {
+  RT_DTexture T = P.textures[tex];
+  if (tx < 0) tx += (float)(-(int)tx + 1);
+  if (ty < 0) ty += (float)(-(int)ty + 1);
+  tx = rt_fractf(tx);
+  ty = rt_fractf(ty);
+  float px = tx * (float)T.width;
+  float py = ty * (float)T.height;
+  int u = (int)px, v = (int)py;
+  if (u > T.width - 1) u = T.width - 1;
+  if (v > T.height - 1) v = T.height - 1;
+  float a = px - (float)u;
+  float b = py - (float)v;
+  int u2 = (u + 1 < T.width) ? u + 1 : u;
+  int v2 = (v + 1 < T.height) ? v + 1 : v;
+  const uint32_t *tp = P.texels + T.offset;
+  rt_v3 c00 = texel_rgb(tp[u + T.stride * v]);
+  rt_v3 c10 = texel_rgb(tp[u2 + T.stride * v]);
+  rt_v3 c01 = texel_rgb(tp[u + T.stride * v2]);
+  rt_v3 c11 = texel_rgb(tp[u2 + T.stride * v2]);
+  rt_v3 c0 = rt_v3_lerp(c00, c10, a);
+  rt_v3 c1 = rt_v3_lerp(c01, c11, a);
+  return rt_v3_lerp(c0, c1, b);
+}
+
+// driver.c:95-104
+__device__ __forceinline__ rt_v3 background_lookup(const RT_KParams &P, rt_v3 dir) {
+  float inv_pi = 1.0f / RT_PI;
+  float inv_two_pi = 1.0f / (2.0f * RT_PI);
+  float u = 0.5f + rt_atan2f(dir.z, dir.x) * inv_two_pi;
+  float v = 0.5f - rt_asinf(dir.y) * inv_pi;
+  return rt_srgb_to_linear(tex_bilinear(P, P.bg_texture, u, v));
+}
+
+// ---------------------------------------------------------------------------------
+// Disney-style BSDF, driver.c:118-348.  Expression order matches oracle/oracle.c.
+
+__device__ __forceinline__ float pow5(float m) { return m * m * m * m * m; }
+__device__ __forceinline__ float luminance(rt_v3 x) { return rt_v3_dot(x, rt_v3_make(0.2126f, 0.7152f, 0.0722f)); }
+
+__device__ __forceinline__ float ggx_D(float roughness, float NoH) {          // driver.c:212-215, k = 2
+  float a2 = roughness * roughness;
+  float d = (NoH * NoH) * (a2 * a2 - 1.0f) + 1.0f;
+  return a2 / (RT_PI * (d * d));
+}
+
+__device__ __forceinline__ float smith_G(float NDotV, float alpha2) {         // driver.c:217-221
+  float a = alpha2 * alpha2;
+  float b = NDotV * NDotV;
+  return (2.0f * NDotV) / (NDotV + rt_sqrtf(a + b - a * b));
+}
+
+__device__ __forceinline__ rt_v3 cosine_hemisphere(uint32_t &rng) {           // driver.c:118-127
+  float angle = rt_rand_f32(&rng) * 2.0f * RT_PI;
+  float distance = rt_sqrtf(rt_rand_f32(&rng));
+  float s, c;
+  rt_sincosf(angle, &s, &c);
+  return rt_v3_make(s * distance, c * distance, rt_sqrtf(1.0f - distance * distance));
+}
+
+__device__ __forceinline__ rt_v3 ggx_vndf(rt_v3 V, float ax, float ay, uint32_t &rng) {  // driver.c:230-250
+  rt_v3 Vh = rt_v3_normalize(rt_v3_make(ax * V.x, ay * V.y, V.z));
+  float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+  rt_v3 T1 = lensq > 0.0f ? rt_v3_scale(rt_v3_make(-Vh.y, Vh.x, 0.0f), 1.0f / rt_sqrtf(lensq)) : rt_v3_make(1, 0, 0);
+  rt_v3 T2 = rt_v3_cross(Vh, T1);
+  float r = rt_sqrtf(rt_rand_f32(&rng));
+  float phi = 2.0f * RT_PI * rt_rand_f32(&rng);
+  float sn, cs;
+  rt_sincosf(phi, &sn, &cs);
+  float t1 = r * cs;
+  float t2 = r * sn;
+  float s = 0.5f * (1.0f + Vh.z);
+  t2 = (1.0f - s) * rt_sqrtf(1.0f - t1 * t1) + s * t2;
+  rt_v3 Nh = rt_v3_add(rt_v3_add(rt_v3_scale(T1, t1), rt_v3_scale(T2, t2)),
+                       rt_v3_scale(Vh, rt_sqrtf(rt_max_ps(0.0f, 1.0f - t1 * t1 - t2 * t2))));
+  return rt_v3_normalize(rt_v3_make(ax * Nh.x, ay * Nh.y, rt_max_ps(0.0f, Nh.z)));
+}
+
+struct BrdfIn {
+  float roughness, metalness, sheen, sheen_tint, aniso2;
+  rt_v3 base_color;
+};
+
+// driver.c:287-348; returns the weight-pdf in brdf_a (<= 0: terminate)
+__device__ __forceinline__ void sample_disney(const BrdfIn &m, rt_v3 in_dir, uint32_t &rng,
+                                              rt_v3 &out_dir, rt_v3 &brdf_rgb, float &brdf_a) {
+  float alpha_x = rt_lerpf(m.roughness * m.roughness, 1.0f, m.aniso2);
+  float alpha_y = m.roughness * m.roughness;
+  rt_v3 micro = ggx_vndf(in_dir, alpha_x, alpha_y, rng);
+
+  rt_v3 f0 = rt_v3_lerp(rt_v3_make(0.04f, 0.04f, 0.04f), m.base_color, m.metalness);
+  float f90 = rt_min_ps(1.0f, (1.0f / 0.04f) * luminance(f0));
+  float theta = rt_v3_dot(in_dir, micro);
+  rt_v3 fresnel = rt_v3_add(f0, rt_v3_scale(rt_v3_sub(rt_v3_make(f90, f90, f90), f0), pow5(1.0f - theta)));
+
+  float dw = 1.0f - m.metalness;
+  float sw = luminance(fresnel);
+  float inv_w = 1.0f / (dw + sw);
+  dw *= inv_w;
+  sw *= inv_w;
+
+  brdf_rgb = rt_v3_make(0, 0, 0);
+  brdf_a = 0.0f;
+  out_dir = rt_v3_make(0, 0, 0);
+  if (rt_rand_f32(&rng) < dw) {
+    out_dir = cosine_hemisphere(rng);
+    micro = rt_v3_normalize(rt_v3_add(out_dir, in_dir));
+    float NoL = out_dir.z, NoV = in_dir.z;
+    if (NoL <= 0.0f || NoV <= 0.0f) return;
+    float LoH = rt_v3_dot(out_dir, micro);
+    float pdf = NoL / RT_PI;
+    float FD90 = 0.5f + 2.0f * m.roughness * LoH * LoH;
+    float fa = 1.0f + (FD90 - 1.0f) * pow5(1.0f - NoL);
+    float fb = 1.0f + (FD90 - 1.0f) * pow5(1.0f - NoV);
+    rt_v3 diff = rt_v3_mul(rt_v3_scale(m.base_color, (fa * fb / RT_PI)), rt_v3_sub(rt_v3_make(1, 1, 1), fresnel));
+    rt_v3 sheen = rt_v3_make(0, 0, 0);
+    if (m.sheen > 0.0f) {                                                     // driver.c:166-183
+      float lum = rt_v3_dot(rt_v3_make(0.3f, 0.6f, 1.0f), m.base_color);
+      rt_v3 tint = (lum > 0.0f) ? rt_v3_scale(m.base_color, 1.0f / lum) : rt_v3_make(1, 1, 1);
+      sheen = rt_v3_scale(rt_v3_lerp(rt_v3_make(1, 1, 1), tint, m.sheen_tint), m.sheen * pow5(1.0f - LoH));
+    }
+    diff = rt_v3_add(diff, sheen);
+    brdf_rgb = rt_v3_make(diff.x * NoL, diff.y * NoL, diff.z * NoL);
+    brdf_a = dw * pdf;
+  } else {
+    out_dir = rt_v3_reflect(rt_v3_scale(in_dir, -1.0f), micro);
+    float NoL = out_dir.z, NoV = in_dir.z;
+    if (NoL <= 0.0f || NoV <= 0.0f) return;
+    NoL = rt_max_ps(NoL, 0.001f);
+    NoV = rt_max_ps(NoV, 0.001f);
+    float NoH = rt_min_ps(micro.z, 0.99f);
+    float D = ggx_D(m.roughness, NoH);
+    float G1 = smith_G(NoV, m.roughness * m.roughness);
+    float pdf = (D * G1) / rt_max_ps(0.00001f, 4.0f * NoV);
+    float a2 = m.roughness * m.roughness;
+    float G = smith_G(NoV, a2) * smith_G(NoL, a2);
+    rt_v3 spec = rt_v3_scale(fresnel, D * G / (4.0f * NoL * NoV));
+    brdf_rgb = rt_v3_make(spec.x * NoL, spec.y * NoL, spec.z * NoL);
+    brdf_a = sw * pdf;
+  }
+  out_dir = rt_v3_normalize(out_dir);
+}
+
+struct ShadeIn {
+  rt_v3 direction, normal, tangent, bitangent;
+  float uvx, uvy;
+};
+
+// driver.c:129-153
+__device__ __forceinline__ rt_v3 normal_map(const RT_KParams &P, int tex, float strength, const ShadeIn &in) {
+  rt_v3 normal = in.normal;
+  if (tex >= 0) {
+    rt_v3 v = tex_bilinear(P, tex, in.uvx, in.uvy);
+    v = rt_v3_add(rt_v3_scale(v, 2.0f), rt_v3_make(-1.0f, -1.0f, -1.0f));
+    v.y *= -1.0f;
+    rt_v3 t = in.tangent, b = in.bitangent, n = in.normal;
+    float s = strength;
+    normal = rt_v3_normalize(rt_v3_make(s * (v.x * t.x + v.y * b.x + v.z * n.x) + n.x * (1.0f - s),
+                                        s * (v.x * t.y + v.y * b.y + v.z * n.y) + n.y * (1.0f - s),
+                                        s * (v.x * t.z + v.y * b.z + v.z * n.z) + n.z * (1.0f - s)));
+  }
+  return normal;
+}
+
+// disney_shader_proc driver.c:350-409 / debug_shader_proc :411-418 on material `mat`
+__device__ __forceinline__ void shade(const RT_KParams &P, int mat, const ShadeIn &in, uint32_t &rng,
+                                      rt_v3 &out_dir, rt_v3 &tint, rt_v3 &emission, bool &terminate,
+                                      LaneCounters &cn) {
+  const float *mb = P.mats + (size_t)mat * 20;
+  float4 m0 = ld4(mb, 0), m1 = ld4(mb, 1), m2 = ld4(mb, 2), m3 = ld4(mb, 3), m4 = ld4(mb, 4);
+  int tex_albedo = as_i(m3.x), tex_normal = as_i(m3.y), tex_mr = as_i(m3.z), tex_em = as_i(m3.w);
+  int kind = as_i(m4.x);
+
+  rt_v3 normal = normal_map(P, tex_normal, m2.x, in);
+  terminate = false;
+  tint = rt_v3_make(0, 0, 0);
+  out_dir = rt_v3_make(0, 0, 0);
+
+  if (kind == RT_MAT_DEBUG) {
+    emission = rt_v3_add(rt_v3_scale(normal, 0.5f), rt_v3_make(0.5f, 0.5f, 0.5f));
+    terminate = true;
+    return;
+  }
+
+  if (tex_albedo >= 0 || tex_normal >= 0 || tex_mr >= 0 || tex_em >= 0) cn.textured += 1;
+
+  rt_v3 base_color = rt_v3_make(m0.x, m0.y, m0.z);
+  if (tex_albedo >= 0) base_color = rt_v3_mul(base_color, rt_srgb_to_linear(tex_bilinear(P, tex_albedo, in.uvx, in.uvy)));
+
+  float roughness = m0.w, metalness = m1.w;
+  if (tex_mr >= 0) {
+    rt_v3 mr = tex_bilinear(P, tex_mr, in.uvx, in.uvy);
+    roughness *= mr.y;
+    metalness *= mr.z;
+  }
+  roughness = rt_clampf(roughness, 0.001f, 1.0f);
+  if (metalness > 0.9f) metalness = 0.9f;
+  metalness /= 0.9f;
+
+  emission = rt_v3_make(m1.x, m1.y, m1.z);
+  if (tex_em >= 0) emission = rt_v3_mul(emission, rt_srgb_to_linear(tex_bilinear(P, tex_em, in.uvx, in.uvy)));
+
+  // basis(), driver.c:155-164
+  rt_v3 t, b;
+  if (rt_absf(rt_v3_dot(normal, in.direction)) < 0.9999f) {
+    t = rt_v3_normalize(rt_v3_cross(normal, in.direction));
+  } else if (rt_absf(rt_v3_dot(normal, rt_v3_make(0, 1, 0))) < 0.9999f) {
+    t = rt_v3_normalize(rt_v3_cross(normal, rt_v3_make(0, 1, 0)));
+  } else {
+    t = rt_v3_normalize(rt_v3_cross(normal, rt_v3_make(1, 0, 0)));
+  }
+  b = rt_v3_cross(normal, t);
+
+  BrdfIn bi;
+  bi.roughness = roughness;
+  bi.metalness = metalness;
+  bi.base_color = base_color;
+  bi.sheen = m2.y;
+  bi.sheen_tint = m2.z;
+  bi.aniso2 = m2.w * m2.w;
+
+  rt_v3 neg = rt_v3_scale(in.direction, -1.0f);
+  rt_v3 in_dir = rt_v3_make(rt_v3_dot(t, neg), rt_v3_dot(b, neg), rt_v3_dot(normal, neg));
+  rt_v3 o, rgb;
+  float a;
+  sample_disney(bi, in_dir, rng, o, rgb, a);
+
+  out_dir = rt_v3_make(t.x * o.x + b.x * o.y + normal.x * o.z,
+                       t.y * o.x + b.y * o.y + normal.y * o.z,
+                       t.z * o.x + b.z * o.y + normal.z * o.z);
+  if (a > 0.0f) {
+    tint = rt_v3_make(rgb.x / a, rgb.y / a, rgb.z / a);
+  } else {
+    terminate = true;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// primary ray of (x, y, sample): raytracer.c:641-694 with exact 1/sqrt
+__device__ __forceinline__ void primary_ray(const RT_KParams &P, int x, int y, int sample, rt_v3 &o, rt_v3 &d) {
+  float inv_width = 1.0f / (float)P.width;
+  float inv_height = 1.0f / (float)P.height;
+  float aspect = (float)P.width / (float)P.height;
+  float jitter = rt_hash12((float)x * 50.0f + (float)sample, (float)y);
+  float uvx = ((float)x + jitter - 0.5f) * 2.0f * inv_width - 1.0f;
+  float uvy = ((float)y + jitter - 0.5f) * 2.0f * inv_height - 1.0f;
+  float dx = uvx * aspect, dy = -uvy, dz = -P.focal_length;
+  float inv_length = 1.0f / rt_sqrtf(dx * dx + dy * dy + dz * dz);
+  float rx = P.cam[0][0] * dx + P.cam[0][1] * dy + P.cam[0][2] * dz;
+  float ry = P.cam[1][0] * dx + P.cam[1][1] * dy + P.cam[1][2] * dz;
+  float rz = P.cam[2][0] * dx + P.cam[2][1] * dy + P.cam[2][2] * dz;
+  o = rt_v3_make(P.cam[0][3], P.cam[1][3], P.cam[2][3]);
+  d = rt_v3_make(rx * inv_length, ry * inv_length, rz * inv_length);
+}
+
+__device__ __forceinline__ void ray_setup(Ray3 &r, rt_v3 o, rt_v3 d) {
+  r.o = o;
+  r.d = d;
+  r.inv_x = 1.0f / d.x;       // raytracer.c:198-202
+  r.inv_y = 1.0f / d.y;
+  r.inv_z = 1.0f / d.z;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// The path-tracing kernel.  Persistent: the grid is sized to the machine, each
+// wave loops over work items until the head counter runs past n_work.
+__global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P) {
+  __shared__ uint32_t s_perm[RT_BLOCK_WAVES][RT_MAX_DEPTH * 64];
+  __shared__ unsigned long long s_acc[RT_BLOCK_WAVES][RT_TILE_PIX * 3];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t *perm = s_perm[wave];
+  unsigned long long *acc = s_acc[wave];
+
+  LaneCounters cn;
+  cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
+
+  acc[lane] = 0ull;
+  acc[lane + 64] = 0ull;
+  acc[lane + 128] = 0ull;
+
+  const int slab = 1 << P.slab_shift;
+  const int item_paths = RT_TILE_PIX << P.slab_shift;
+
+  for (;;) {
+    // ---- dequeue one work item (wave-uniform) ----
+    uint32_t w = 0;
+    if (lane == 0) w = atomicAdd(P.work_head, 1u);
+    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    if (w >= (uint32_t)P.n_work) break;
+
+    // item -> (local chunk, 8x8 tile inside the chunk, slab of samples)
+    const int slab_idx = (int)(w % (uint32_t)P.n_slabs);
+    const int tile_idx = (int)(w / (uint32_t)P.n_slabs);
+    const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
+    const int chunk = lchunk * P.world + P.rank;
+    const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
+    const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
+    if (tile_x0 >= P.width || tile_y0 >= P.height) continue;   // tile entirely outside
+    const int s_base = slab_idx << P.slab_shift;
+
+    // ---- path state ----
+    bool  alive = false;
+    int   pix = 0, bounce = 0;
+    uint32_t rng = 0;
+    rt_v3 org = rt_v3_make(0, 0, 0), dir = rt_v3_make(0, 0, 1);
+    rt_v3 tint = rt_v3_make(1, 1, 1), emis = rt_v3_make(0, 0, 0);
+    int next_k = 0;      // wave-uniform
+
+    for (;;) {
+      // ---- regenerate: dead lanes take the next (pixel, sample) of the item ----
+      if (next_k < item_paths) {
+        unsigned long long need = __ballot(!alive);
+        if (need) {
+          int my_k = next_k + (int)__popcll(need & ((1ull << lane) - 1ull));
+          next_k += (int)__popcll(need);
+          if (!alive && my_k < item_paths) {
+            int p = my_k >> P.slab_shift;
+            int s = s_base + (my_k & (slab - 1));
+            int x = tile_x0 + (p & 7), y = tile_y0 + (p >> 3);
+            if (s < P.samples && x < P.width && y < P.height && P.max_bounces > 0) {
+              alive = true;
+              pix = p;
+              bounce = 0;
+              rng = rt_path_seed(P.seed, (uint32_t)(x + y * P.width), (uint32_t)s);
+              primary_ray(P, x, y, s, org, dir);
+              tint = rt_v3_make(1, 1, 1);
+              emis = rt_v3_make(0, 0, 0);
+              cn.paths += 1;
+            }
+          }
+        }
+      }
+      if (!__any(alive)) {
+        if (next_k >= item_paths) break;
+        continue;
+      }
+
+      // ---- extend: closest hit of every live path ----
+      HitRec hit;
+      hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+      Ray3 ray;
+      ray_setup(ray, org, dir);
+      if (alive) trace_ray(P, ray, hit, perm, lane, cn);
+
+      // ---- shade / environment ----
+      bool  done = false;
+      rt_v3 radiance = rt_v3_make(0, 0, 0);
+      if (alive) {
+        if (hit.tri >= 0) {
+          const float *tb = P.tris + (size_t)hit.tri * 28;
+          float4 q0 = ld4(tb, 0), q1 = ld4(tb, 1), q2 = ld4(tb, 2), q3 = ld4(tb, 3);
+          float4 q4 = ld4(tb, 4), q5 = ld4(tb, 5), q6 = ld4(tb, 6);
+          float t1 = hit.u, t2 = hit.v;
+          float t0 = 1.0f - t1 - t2;
+          rt_v3 point = rt_v3_add(org, rt_v3_scale(dir, hit.t));
+          rt_v3 n_geo = rt_v3_make(q0.x, q0.y, q0.z);
+          rt_v3 n_int = rt_v3_make(q1.x * t0 + q2.x * t1 + q3.x * t2,
+                                   q1.y * t0 + q2.y * t1 + q3.y * t2,
+                                   q1.z * t0 + q2.z * t1 + q3.z * t2);
+          if (rt_v3_dot(n_geo, dir) > 0.0f || rt_v3_dot(n_int, dir) > 0.0f) {
+            // back face: pass through, costs a bounce (raytracer.c:516-522)
+            org = rt_v3_add(point, rt_v3_scale(dir, RT_EPS));
+          } else {
+            ShadeIn in;
+            in.direction = dir;
+            in.normal = rt_v3_normalize(n_int);
+            in.tangent = rt_v3_make(q4.x, q4.y, q4.z);
+            in.bitangent = rt_v3_make(q5.x, q5.y, q5.z);
+            in.uvx = q1.w * t0 + q3.w * t1 + q5.w * t2;
+            in.uvy = q2.w * t0 + q4.w * t1 + q6.x * t2;
+            rt_v3 out_dir, s_tint, s_emis;
+            bool terminate;
+            cn.shades += 1;
+            shade(P, as_i(q0.w), in, rng, out_dir, s_tint, s_emis, terminate, cn);
+            emis = rt_v3_add(emis, rt_v3_mul(s_emis, tint));
+            if (terminate) {
+              done = true;
+              radiance = emis;
+            } else {
+              dir = out_dir;
+              tint = rt_v3_mul(tint, s_tint);
+              float below = (rt_v3_dot(n_geo, out_dir) < 0.0f) ? 1.0f : 0.0f;
+              float bias = (0.5f - below) * 2.0f * RT_EPS;
+              org = rt_v3_add(point, rt_v3_scale(n_geo, bias));
+            }
+          }
+          if (!done) {
+            bounce += 1;
+            if (bounce >= P.max_bounces) {     // bounces exhausted: emission only (raytracer.c:557)
+              done = true;
+              radiance = emis;
+            }
+          }
+        } else {
+          cn.bgs += 1;
+          rt_v3 bg = background_lookup(P, dir);
+          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
+          done = true;
+        }
+      }
+      if (done) {
+        atomicAdd(&acc[pix * 3 + 0], (unsigned long long)rt_accum_quantize(radiance.x));
+        atomicAdd(&acc[pix * 3 + 1], (unsigned long long)rt_accum_quantize(radiance.y));
+        atomicAdd(&acc[pix * 3 + 2], (unsigned long long)rt_accum_quantize(radiance.z));
+        alive = false;
+      }
+    }
+
+    // ---- flush the tile: lane p owns pixel p ----
+    {
+      int x = tile_x0 + (lane & 7), y = tile_y0 + (lane >> 3);
+      unsigned long long r = acc[lane * 3 + 0], g = acc[lane * 3 + 1], b = acc[lane * 3 + 2];
+      acc[lane * 3 + 0] = 0ull;
+      acc[lane * 3 + 1] = 0ull;
+      acc[lane * 3 + 2] = 0ull;
+      if (x < P.width && y < P.height) {
+        unsigned long long *dst = P.accum + ((size_t)y * P.width + x) * 3;
+        atomicAdd(dst + 0, r);
+        atomicAdd(dst + 1, g);
+        atomicAdd(dst + 2, b);
+      }
+    }
+  }
+
+  // ---- counters: one atomic per wave and counter ----
+  uint32_t c0 = wave_sum(cn.paths), c1 = wave_sum(cn.rays), c2 = wave_sum(cn.nodes), c3 = wave_sum(cn.leaves);
+  uint32_t c4 = wave_sum(cn.shades), c5 = wave_sum(cn.bgs), c6 = wave_sum(cn.textured);
+  if (lane == 0) {
+    atomicAdd(P.counters + CNT_PATHS, (unsigned long long)c0);
+    atomicAdd(P.counters + CNT_RAYS, (unsigned long long)c1);
+    atomicAdd(P.counters + CNT_NODES, (unsigned long long)c2);
+    atomicAdd(P.counters + CNT_LEAVES, (unsigned long long)c3);
+    atomicAdd(P.counters + CNT_SHADES, (unsigned long long)c4);
+    atomicAdd(P.counters + CNT_BG, (unsigned long long)c5);
+    atomicAdd(P.counters + CNT_TEXTURED, (unsigned long long)c6);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// accum -> mean -> clamp -> sRGB -> u8 (raytracer.c:700-716), one thread per pixel
+// of this rank's chunks.
+__global__ void rt_resolve_kernel(int width, int height, int samples, int chunks_x, int rank, int world,
+                                  int n_local_chunks, const unsigned long long *accum,
+                                  uint8_t *tiles, uint8_t *image, float *linear) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_local_chunks * 1024) return;
+  int lchunk = idx >> 10, p = idx & 1023;
+  int chunk = lchunk * world + rank;
+  int x = (chunk % chunks_x) * 32 + (p & 31);
+  int y = (chunk / chunks_x) * 32 + (p >> 5);
+  uint8_t rgb[3] = {0, 0, 0};
+  if (x < width && y < height) {
+    size_t pix = (size_t)y * width + x;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float lin = rt_accum_resolve(accum[pix * 3 + c], (uint32_t)samples);
+      if (linear) linear[pix * 3 + c] = lin;
+      rgb[c] = rt_encode_u8(lin);
+      if (image) image[pix * 3 + c] = rgb[c];
+    }
+  }
+  if (tiles) {
+    tiles[(size_t)idx * 3 + 0] = rgb[0];
+    tiles[(size_t)idx * 3 + 1] = rgb[1];
+    tiles[(size_t)idx * 3 + 2] = rgb[2];
+  }
+}
+
+// gathered compact tiles [world][max_local][1024*3] -> row-major image
+__global__ void rt_untile_kernel(int width, int height, int chunks_x, int n_chunks, int world, int max_local,
+                                 const uint8_t *all_tiles, uint8_t *image) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_chunks * 1024) return;
+  int chunk = idx >> 10, p = idx & 1023;
+  int x = (chunk % chunks_x) * 32 + (p & 31);
+  int y = (chunk / chunks_x) * 32 + (p >> 5);
+  if (x >= width || y >= height) return;
+  int rank = chunk % world, lchunk = chunk / world;
+  const uint8_t *src = all_tiles + (((size_t)rank * max_local + lchunk) * 1024 + p) * 3;
+  uint8_t *dst = image + ((size_t)y * width + x) * 3;
+  dst[0] = src[0];
+  dst[1] = src[1];
+  dst[2] = src[2];
+}
+
+// ---------------------------------------------------------------------------------
+// unit-level kernels for parity tests
+
+__global__ void rt_test_math_kernel(int op, int n, const float *x, const float *y, float *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = x[i], b = y ? y[i] : 0.0f, s, c;
+  float r = 0.0f;
+  switch (op) {
+  case 0: r = rt_logf(a); break;
+  case 1: r = rt_expf(a); break;
+  case 2: r = rt_powf(a, b); break;
+  case 3: rt_sincosf(a, &s, &c); r = s; break;
+  case 4: rt_sincosf(a, &s, &c); r = c; break;
+  case 5: r = rt_atan2f(a, b); break;
+  case 6: r = rt_asinf(a); break;
+  case 7: r = rt_srgb_to_linear1(a); break;
+  case 8: r = rt_linear_to_srgb(a); break;
+  case 9: r = rt_sqrtf(a); break;
+  case 10: r = 1.0f / a; break;
+  default: break;
+  }
+  out[i] = r;
+}
+
+__global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_test_trace_kernel(RT_KParams P, int n, const float *rays,
+                                                                         float *out_t, int *out_tri, float *out_uv) {
+  __shared__ uint32_t s_perm[RT_BLOCK_WAVES][RT_MAX_DEPTH * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  LaneCounters cn;
+  cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
+  if (i >= n) return;
+  Ray3 r;
+  ray_setup(r, rt_v3_make(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]),
+            rt_v3_make(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
+  HitRec hit;
+  trace_ray(P, r, hit, s_perm[wave], lane, cn);
+  out_t[i] = hit.t;
+  out_tri[i] = hit.tri;
+  out_uv[i * 2 + 0] = hit.u;
+  out_uv[i * 2 + 1] = hit.v;
+}
+
+__global__ void rt_test_texture_kernel(RT_KParams P, int tex, int n, const float *uv, float *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rt_v3 c = tex_bilinear(P, tex, uv[i * 2], uv[i * 2 + 1]);
+  out[i * 3 + 0] = c.x;
+  out[i * 3 + 1] = c.y;
+  out[i * 3 + 2] = c.z;
+}
+
+// ---------------------------------------------------------------------------------
+// launchers (called from rt_api.cpp)
+
+extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_path_kernel, dim3(n_blocks), dim3(RT_BLOCK_THREADS), 0, stream, *P);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_resolve(int width, int height, int samples, int chunks_x, int rank, int world,
+                                 int n_local_chunks, const unsigned long long *accum, uint8_t *tiles,
+                                 uint8_t *image, float *linear, hipStream_t stream) {
+  int n = n_local_chunks * 1024;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(rt_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, width, height, samples,
+                     chunks_x, rank, world, n_local_chunks, accum, tiles, image, linear);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, int world, int max_local,
+                                const uint8_t *all_tiles, uint8_t *image, hipStream_t stream) {
+  int n = n_chunks * 1024;
+  hipLaunchKernelGGL(rt_untile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, width, height, chunks_x,
+                     n_chunks, world, max_local, all_tiles, image);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_test_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, n, x, y, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri,
+                                    float *out_uv, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_test_trace_kernel, dim3((n + RT_BLOCK_THREADS - 1) / RT_BLOCK_THREADS),
+                     dim3(RT_BLOCK_THREADS), 0, stream, *P, n, rays, out_t, out_tri, out_uv);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out,
+                                      hipStream_t stream) {
+  hipLaunchKernelGGL(rt_test_texture_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *P, tex, n, uv, out);
+  return (int)hipGetLastError();
+}

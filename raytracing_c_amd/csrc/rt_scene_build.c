@@ -1,0 +1,267 @@
+/* rt_scene_build.c -- host-side construction of the implicit 8-ary BVH and the
+ * SoA+AoS triangle block that the render path consumes.
+ *
+ * Replaces reference scene.c:78-242,311-426 (scene_init and what it calls).
+ * This stays on the CPU: the GPU only ever reads the finished layout
+ * (SURVEY.md section 8f #2).  Same layout, same split rule, with two defect
+ * fixes that include/rt_scene.h documents (early-leaf chain, depth 0) and two
+ * choices the reference leaves open: the sort is a STABLE merge sort (codin
+ * sort_slice_by is unspecified) and the build is single threaded (the
+ * reference's 12 builder threads write disjoint node slots, so the result does
+ * not depend on threading).
+ */
+#include "../../include/rt_scene.h"
+#include "../../include/rt_math.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static rawptr rt_alloc_zeroed(Allocator a, isize size, isize align) {
+  if (size <= 0) size = align;
+  rawptr p;
+  if (a.proc) {
+    p = a.proc(a.user, size, align);
+  } else {
+    isize rounded = (size + align - 1) / align * align;
+    p = aligned_alloc((size_t)align, (size_t)rounded);
+  }
+  if (p) memset(p, 0, (size_t)size);
+  return p;
+}
+
+/* scene.c:78-99: one allocation, nine coordinate arrays then the AoS records */
+static bool triangles_init(Triangles *triangles, isize len, Allocator allocator) {
+  while (len % RT_BVH_WIDTH) len += 1;
+  triangles->len = (i32)len;
+  f32 *data = (f32 *)rt_alloc_zeroed(allocator, TRIANGLES_ALLOCATION_SIZE(len), 64);
+  if (!data) return false;
+  for (int k = 0; k < 3; k++) {
+    triangles->x[k] = data + len * (0 + k);
+    triangles->y[k] = data + len * (3 + k);
+    triangles->z[k] = data + len * (6 + k);
+  }
+  triangles->aos = (Triangle_AOS *)(data + len * 9);
+  return true;
+}
+
+static rt_v3 P(Vec3 v) { return rt_v3_make(v.x, v.y, v.z); }
+static Vec3 Q(rt_v3 v) { Vec3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
+
+/* scene.c:105-155: copy positions to the SoA arrays and precompute the face
+ * normal and the UV-aligned tangent frame of every triangle */
+static void triangles_insert(Triangles *triangles, Triangle const *v, isize count, isize offset) {
+  for (isize i = 0; i < count; i++) {
+    Triangle const *t = &v[i];
+    for (int k = 0; k < 3; k++) {
+      triangles->x[k][offset + i] = t->positions[k].x;
+      triangles->y[k][offset + i] = t->positions[k].y;
+      triangles->z[k][offset + i] = t->positions[k].z;
+    }
+
+    rt_v3 edge1 = rt_v3_sub(P(t->positions[1]), P(t->positions[0]));
+    rt_v3 edge2 = rt_v3_sub(P(t->positions[2]), P(t->positions[0]));
+
+    f32 du1 = t->tex_coords[1].x - t->tex_coords[0].x, dv1 = t->tex_coords[1].y - t->tex_coords[0].y;
+    f32 du2 = t->tex_coords[2].x - t->tex_coords[0].x, dv2 = t->tex_coords[2].y - t->tex_coords[0].y;
+
+    f32 d = du1 * dv2 - du2 * dv1;
+    if (rt_absf(d) < 0.0001f) d = (d < 0) ? -0.0001f : 0.0001f;
+    f32 inv_d = 1.0f / d;
+
+    rt_v3 tangent   = rt_v3_normalize(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge1, dv2), rt_v3_scale(edge2, dv1)), inv_d));
+    rt_v3 bitangent = rt_v3_normalize(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge2, du1), rt_v3_scale(edge1, du2)), inv_d));
+
+    Triangle_AOS *aos = &triangles->aos[offset + i];
+    aos->shader       = t->shader;
+    aos->normal       = Q(rt_v3_normalize(rt_v3_cross(edge1, edge2)));
+    aos->normal_a     = t->normals[0];
+    aos->normal_b     = t->normals[1];
+    aos->normal_c     = t->normals[2];
+    aos->tex_coords_a = t->tex_coords[0];
+    aos->tex_coords_b = t->tex_coords[1];
+    aos->tex_coords_c = t->tex_coords[2];
+    aos->tangent      = Q(tangent);
+    aos->bitangent    = Q(bitangent);
+  }
+}
+
+/* scene.c:157-201 */
+static f32 aabb_surface_area(AABB const *aabb) {
+  f32 x = aabb->max.x - aabb->min.x;
+  f32 y = aabb->max.y - aabb->min.y;
+  f32 z = aabb->max.z - aabb->min.z;
+  return 2.0f * (x * y + y * z + z * x);
+}
+
+static f32 min3f(f32 a, f32 b, f32 c) { f32 m = b < c ? b : c; return a < m ? a : m; }
+static f32 max3f(f32 a, f32 b, f32 c) { f32 m = b > c ? b : c; return a > m ? a : m; }
+
+static void aabb_triangle(Triangle const *t, AABB *aabb) {
+  for (int ax = 0; ax < 3; ax++) {
+    aabb->min.data[ax] = min3f(t->positions[0].data[ax], t->positions[1].data[ax], t->positions[2].data[ax]) - RT_EPSILON;
+    aabb->max.data[ax] = max3f(t->positions[0].data[ax], t->positions[1].data[ax], t->positions[2].data[ax]) + RT_EPSILON;
+  }
+}
+
+static void aabb_triangle_slice(Triangle const *tris, isize count, AABB *aabb) {
+  memset(aabb, 0, sizeof *aabb);
+  for (isize i = 0; i < count; i++) {
+    AABB t;
+    aabb_triangle(&tris[i], &t);
+    if (i == 0) *aabb = t;
+    for (int ax = 0; ax < 3; ax++) {
+      if (t.min.data[ax] < aabb->min.data[ax]) aabb->min.data[ax] = t.min.data[ax];
+      if (t.max.data[ax] > aabb->max.data[ax]) aabb->max.data[ax] = t.max.data[ax];
+    }
+  }
+}
+
+/* scene.c:203-222: ascending by the sum of the three vertex coordinates on
+ * `axis`; stable merge sort on (key, position) */
+typedef struct { f32 key; i32 idx; } Sort_Key;
+
+static void merge_sort_keys(Sort_Key *a, Sort_Key *tmp, isize n) {
+  if (n < 2) return;
+  isize h = n / 2;
+  merge_sort_keys(a, tmp, h);
+  merge_sort_keys(a + h, tmp, n - h);
+  isize i = 0, j = h, k = 0;
+  while (i < h && j < n) tmp[k++] = (a[j].key < a[i].key) ? a[j++] : a[i++];
+  while (i < h) tmp[k++] = a[i++];
+  while (j < n) tmp[k++] = a[j++];
+  memcpy(a, tmp, (size_t)n * sizeof *a);
+}
+
+typedef struct {
+  Sort_Key *keys, *tmp;
+  Triangle *scratch;
+} Sort_Buffers;
+
+static void sort_triangle_slice(Triangle *tris, isize count, int axis, Sort_Buffers *sb) {
+  for (isize i = 0; i < count; i++) {
+    sb->keys[i].key = tris[i].positions[0].data[axis] + tris[i].positions[1].data[axis] + tris[i].positions[2].data[axis];
+    sb->keys[i].idx = (i32)i;
+  }
+  merge_sort_keys(sb->keys, sb->tmp, count);
+  for (isize i = 0; i < count; i++) sb->scratch[i] = tris[sb->keys[i].idx];
+  memcpy(tris, sb->scratch, (size_t)count * sizeof *tris);
+}
+
+/* scene.c:224-242 */
+static isize bvh_required_depth(isize n_triangles) {
+  n_triangles = (n_triangles + RT_BVH_WIDTH - 1) / RT_BVH_WIDTH;
+  isize n = 1, i = 0;
+  while (n < n_triangles) { n *= RT_BVH_WIDTH; i += 1; }
+  return i;
+}
+
+static isize bvh_partition_triangles(isize n_triangles, isize per_child) {
+  isize n = 0, left = n_triangles;
+  while (n < n_triangles / 2 && left > per_child) { n += per_child; left -= per_child; }
+  return n;
+}
+
+typedef struct { Triangle *data; isize len; } Tri_Span;
+
+/* scene.c:311-414: fixed-capacity split of `tris` into at most 8 children of
+ * capacity 8^depth triangles each; `depth` = internal levels at and below
+ * `index` (0 = `index` is a leaf group) */
+static void bvh_build(Scene *scene, Triangle *tris, isize count, isize depth, BVH_Index index, Sort_Buffers *sb) {
+  if (count <= RT_BVH_WIDTH) {
+    if (depth == 0) {
+      triangles_insert(&scene->triangles, tris, count, ((isize)index - scene->bvh.last_row_offset) * RT_BVH_WIDTH);
+      return;
+    }
+    /* early-leaf fix: hand the small set down through child 0 (reference
+     * scene.c:318-321 would write at a negative triangle offset here) */
+    if (count == 0) return;
+    AABB aabb;
+    aabb_triangle_slice(tris, count, &aabb);
+    BVH_Node *node = &scene->bvh.nodes.data[index];
+    node->min_x[0] = aabb.min.x; node->min_y[0] = aabb.min.y; node->min_z[0] = aabb.min.z;
+    node->max_x[0] = aabb.max.x; node->max_y[0] = aabb.max.y; node->max_z[0] = aabb.max.z;
+    bvh_build(scene, tris, count, depth - 1, index * RT_BVH_WIDTH + 1, sb);
+    return;
+  }
+
+  isize per_child = bvh_n_leaf_nodes(depth);
+
+  Tri_Span slices[RT_BVH_WIDTH];
+  Tri_Span finished[RT_BVH_WIDTH];
+  isize n_slices = 1, n_finished = 0;
+  slices[0].data = tris;
+  slices[0].len  = count;
+
+  while (n_slices != 0) {
+    n_slices -= 1;
+    Tri_Span slice = slices[n_slices];
+    isize split = bvh_partition_triangles(slice.len, per_child);
+    Tri_Span left  = { slice.data, split };
+    Tri_Span right = { slice.data + split, slice.len - split };
+
+    f32 min_surface_area = RT_INF;
+    int best_axis = 0;
+    for (int axis = 0; axis < 3; axis++) {
+      sort_triangle_slice(slice.data, slice.len, axis, sb);
+      AABB a, b;
+      aabb_triangle_slice(left.data, left.len, &a);
+      aabb_triangle_slice(right.data, right.len, &b);
+      f32 surface_area = aabb_surface_area(&a) + aabb_surface_area(&b);
+      if (surface_area <= min_surface_area) {
+        min_surface_area = surface_area;
+        best_axis = axis;
+      }
+    }
+    if (best_axis != 2) sort_triangle_slice(slice.data, slice.len, best_axis, sb);
+
+    if (left.len > per_child) slices[n_slices++] = left;
+    else if (left.len)        finished[n_finished++] = left;
+    if (right.len > per_child) slices[n_slices++] = right;
+    else if (right.len)        finished[n_finished++] = right;
+  }
+
+  BVH_Node node;
+  memset(&node, 0, sizeof node);
+  for (isize i = 0; i < n_finished; i++) {
+    AABB aabb;
+    aabb_triangle_slice(finished[i].data, finished[i].len, &aabb);
+    node.min_x[i] = aabb.min.x; node.min_y[i] = aabb.min.y; node.min_z[i] = aabb.min.z;
+    node.max_x[i] = aabb.max.x; node.max_y[i] = aabb.max.y; node.max_z[i] = aabb.max.z;
+    bvh_build(scene, finished[i].data, finished[i].len, depth - 1, index * RT_BVH_WIDTH + 1 + (BVH_Index)i, sb);
+  }
+  scene->bvh.nodes.data[index] = node;
+}
+
+/* scene.c:416-426.  Sorts a private copy of the input (the reference sorts the
+ * caller's slice in place). */
+void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
+  isize depth      = bvh_required_depth(src.len);
+  isize n_internal = bvh_n_internal_nodes(depth);
+  scene->bvh.depth           = depth;
+  scene->bvh.last_row_offset = n_internal;
+  scene->bvh.nodes.len       = n_internal;
+  scene->bvh.nodes.data      = (BVH_Node *)rt_alloc_zeroed(allocator, n_internal * (isize)sizeof(BVH_Node), 64);
+  if (!triangles_init(&scene->triangles, bvh_n_leaf_nodes(depth) * RT_BVH_WIDTH, allocator)) return;
+  if (src.len <= 0) return;
+
+  isize n = src.len;
+  Triangle *work = (Triangle *)malloc((size_t)n * sizeof *work);
+  Sort_Buffers sb;
+  sb.keys    = (Sort_Key *)malloc((size_t)n * sizeof *sb.keys);
+  sb.tmp     = (Sort_Key *)malloc((size_t)n * sizeof *sb.tmp);
+  sb.scratch = (Triangle *)malloc((size_t)n * sizeof *sb.scratch);
+  if (work && sb.keys && sb.tmp && sb.scratch) {
+    memcpy(work, src.data, (size_t)n * sizeof *work);
+    bvh_build(scene, work, n, depth, 0, &sb);
+  }
+  free(work); free(sb.keys); free(sb.tmp); free(sb.scratch);
+}
+
+void rt_scene_free(Scene *scene) {
+  if (!scene) return;
+  free(scene->bvh.nodes.data);
+  free(scene->triangles.x[0]);
+  scene->bvh.nodes.data = NULL;
+  scene->bvh.nodes.len  = 0;
+  memset(&scene->triangles, 0, sizeof scene->triangles);
+}

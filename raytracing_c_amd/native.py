@@ -1,0 +1,94 @@
+"""Loads librt_hip.so (built in-tree by raytracing_c_amd/csrc/Makefile) and declares prototypes.
+
+There is no Python or CPU implementation behind this module: if the shared library is missing
+the import of `lib` raises NativeLibraryMissing.
+"""
+import ctypes as C
+import os
+
+from . import ctypes_abi as abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class _Lazy:
+    """Resolves the shared library on first attribute access."""
+
+    def __init__(self):
+        self._dll = None
+
+    def _load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `make -C raytracing_c_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback for the render path")
+        dll = C.CDLL(LIB_PATH)
+        _declare(dll)
+        self._dll = dll
+        return dll
+
+    def __getattr__(self, name):
+        return getattr(self._load(), name)
+
+
+def _declare(d):
+    P = C.POINTER
+    vp = C.c_void_p
+    d.rt_last_error.restype = C.c_char_p
+    d.rt_clear_error.restype = None
+    d.rt_init.argtypes = [C.c_int]
+    d.rt_set_seed.argtypes = [C.c_uint32]
+    d.rt_set_seed.restype = None
+    d.rt_get_seed.restype = C.c_uint32
+    d.scene_init.argtypes = [P(abi.Scene), abi.Triangle_Slice, abi.Allocator]
+    d.scene_init.restype = None
+    d.rt_scene_free.argtypes = [P(abi.Scene)]
+    d.rt_scene_free.restype = None
+    d.rt_scene_upload.argtypes = [P(abi.Scene)]
+    d.rt_scene_upload.restype = vp
+    d.rt_scene_release.argtypes = [vp]
+    d.rt_scene_release.restype = None
+    d.rt_scene_invalidate.argtypes = [P(abi.Scene)]
+    d.rt_scene_invalidate.restype = None
+    d.rt_scene_device_bytes.argtypes = [vp]
+    d.rt_scene_device_bytes.restype = C.c_int64
+    d.rt_set_camera.argtypes = [vp, P(abi.Camera)]
+    d.rt_chunk_count.argtypes = [C.c_int32, C.c_int32]
+    d.rt_local_chunk_count.argtypes = [C.c_int32] * 4
+    d.rt_render_accumulate.argtypes = [vp, P(abi.RT_Render_Params), vp, vp]
+    d.rt_resolve.argtypes = [P(abi.RT_Render_Params), vp, vp, vp, vp, vp]
+    d.rt_untile.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    d.rt_render_frame.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, vp, vp]
+    d.rt_get_counters.argtypes = [P(abi.RT_Counters)]
+    d.rt_last_kernel_ms.restype = C.c_float
+    d.rt_test_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
+    d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    d.render_thread_proc.argtypes = [P(abi.Rendering_Context)]
+    d.render_thread_proc.restype = None
+    d.rendering_context_is_finished.argtypes = [P(abi.Rendering_Context)]
+    d.rendering_context_is_finished.restype = C.c_bool
+    d.rendering_context_finish.argtypes = [P(abi.Rendering_Context)]
+    d.rendering_context_finish.restype = None
+    d.render.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize]
+    d.lightmap_bake.argtypes = [P(abi.Image), P(abi.Scene), abi.isize]
+    d.lightmap_bake.restype = None
+
+
+lib = _Lazy()
+
+
+def symbol_address(name):
+    """Address of an exported function (used as Shader.proc / Background.proc token)."""
+    return C.cast(getattr(lib, name), C.c_void_p).value
+
+
+def last_error():
+    return (lib.rt_last_error() or b"").decode("utf-8", "replace")

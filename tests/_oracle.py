@@ -1,0 +1,121 @@
+"""ctypes access to oracle/liboracle.so -- the CPU checker.  TEST INFRASTRUCTURE ONLY.
+
+Nothing under raytracing_c_amd/ may import this module (oracle/oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracing_c_amd import ctypes_abi as abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class Oracle_Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured")]
+
+
+class Oracle_Config(C.Structure):
+    _fields_ = [("disney_proc", C.c_void_p), ("debug_proc", C.c_void_p), ("background_proc", C.c_void_p),
+                ("seed", C.c_uint32), ("accum_mode", C.c_int32), ("n_threads", C.c_int32),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
+                ("sample0", C.c_int32), ("sample_count", C.c_int32)]
+
+
+_dll = None
+
+
+def load(path=None):
+    global _dll
+    if _dll is not None and path is None:
+        return _dll
+    p = path or LIB
+    if not os.path.exists(p):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    d = C.CDLL(p)
+    P = C.POINTER
+    vp = C.c_void_p
+    d.oracle_render.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, P(Oracle_Config), vp, vp,
+                                P(Oracle_Counters)]
+    d.oracle_trace_path.argtypes = [P(abi.Scene), P(Oracle_Config)] + [C.c_int32] * 7 + [vp]
+    d.oracle_trace_path.restype = None
+    d.oracle_rand_u32_seq.argtypes = [C.c_uint32, C.c_int32, vp]
+    d.oracle_rand_u32_seq.restype = None
+    d.oracle_rand_f32_seq.argtypes = [C.c_uint32, C.c_int32, vp]
+    d.oracle_rand_f32_seq.restype = None
+    d.oracle_hash12.argtypes = [C.c_float, C.c_float]
+    d.oracle_hash12.restype = C.c_float
+    d.oracle_ray_aabbs_hit_8.argtypes = [P(abi.Ray), C.c_float, C.c_float, P(abi.BVH_Node), vp]
+    d.oracle_ray_aabbs_hit_8.restype = None
+    d.oracle_ray_triangles_hit_8.argtypes = [P(abi.Ray), P(abi.Triangles), abi.isize, P(abi.Hit), P(C.c_int32)]
+    d.oracle_ray_triangles_hit_8.restype = C.c_bool
+    d.oracle_ray_scene_hit.argtypes = [P(abi.Ray), P(abi.Scene), P(abi.Hit), P(C.c_int32)]
+    d.oracle_ray_scene_hit.restype = None
+    d.oracle_sample_texture_bilinear.argtypes = [P(abi.Image), C.c_float, C.c_float, vp]
+    d.oracle_sample_texture_bilinear.restype = None
+    d.oracle_sample_background.argtypes = [P(abi.Image), vp, vp]
+    d.oracle_sample_background.restype = None
+    d.oracle_sample_disney_brdf.argtypes = [C.c_float] * 5 + [vp, vp, P(C.c_uint32), vp, vp]
+    d.oracle_sample_disney_brdf.restype = None
+    d.oracle_disney_shade.argtypes = [P(abi.PBR_Shader_Data), P(abi.Shader_Input), P(C.c_uint32), P(abi.Shader_Output)]
+    d.oracle_disney_shade.restype = None
+    d.oracle_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
+    d.oracle_math.restype = None
+    d.oracle_encode_u8.argtypes = [C.c_float]
+    d.oracle_encode_u8.restype = C.c_uint8
+    if path is None:
+        _dll = d
+    return d
+
+
+def config_for(hs, seed=0x1234ABCD, n_threads=8, accum_mode=0, window=None, samples=None):
+    """Oracle_Config whose built-in material addresses are the product's exported tokens."""
+    from raytracing_c_amd.native import symbol_address
+    cfg = Oracle_Config()
+    cfg.disney_proc = symbol_address("disney_shader_proc")
+    cfg.debug_proc = symbol_address("debug_shader_proc")
+    cfg.background_proc = symbol_address("sample_background")
+    cfg.seed = seed
+    cfg.accum_mode = accum_mode
+    cfg.n_threads = n_threads
+    if window:
+        cfg.x0, cfg.y0, cfg.x1, cfg.y1 = window
+    if samples:
+        cfg.sample0, cfg.sample_count = samples
+    return cfg
+
+
+def render(hs, width, height, samples, max_bounces, seed=0x1234ABCD, n_threads=8, accum_mode=0, window=None,
+           sample_range=None, lib=None):
+    """Oracle render -> dict(image, linear, accum, counters)."""
+    d = lib or load()
+    out = np.zeros((height, width, 3), np.uint8)
+    img = abi.Image()
+    img.components, img.pixel_type, img.width, img.stride, img.height = 3, 0, width, width, height
+    img.pixels.data, img.pixels.len = out.ctypes.data, out.size
+    linear = np.zeros((height, width, 3), np.float32)
+    accum = np.zeros((height, width, 3), np.uint64)
+    cfg = config_for(hs, seed, n_threads, accum_mode, window, sample_range)
+    cnt = Oracle_Counters()
+    rc = d.oracle_render(C.byref(hs.scene), C.byref(img), samples, max_bounces, C.byref(cfg), linear.ctypes.data,
+                         accum.ctypes.data, C.byref(cnt))
+    assert rc == 0
+    counters = {f[0]: int(getattr(cnt, f[0])) for f in cnt._fields_}
+    return dict(image=out, linear=linear, accum=accum, counters=counters)
+
+
+def math(op, x, y=None, lib=None):
+    d = lib or load()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, np.float32)
+        yp = y.ctypes.data
+    d.oracle_math(op, x.size, x.ctypes.data, yp, out.ctypes.data)
+    return out
