@@ -19,6 +19,7 @@
 
 static _Thread_local u32             random_state;
 static _Thread_local Oracle_Counters tl_counters;
+static _Thread_local f32             tl_bary_u, tl_bary_v;   /* barycentrics of the last accepted hit */
 
 static inline f32 rand_f32(void) { return rt_rand_f32(&random_state); }
 
@@ -85,6 +86,8 @@ static bool ray_triangles_hit_8(Ray const *ray, Triangles const *triangles, isiz
     f32 t1 = us[triangle_index];
     f32 t2 = vs[triangle_index];
     f32 t0 = 1.0f - t1 - t2;
+    tl_bary_u = t1;
+    tl_bary_v = t2;
 
     hit->point = U(rt_v3_add(org, rt_v3_scale(dir, min)));
     hit->normal.x = aos->normal_a.x * t0 + aos->normal_b.x * t1 + aos->normal_c.x * t2;
@@ -729,6 +732,23 @@ bool oracle_ray_triangles_hit_8(Ray const *ray, Triangles const *tris, isize off
 void oracle_ray_scene_hit(Ray const *ray, Scene const *scene, Hit *hit, i32 *triangle) {
   if (triangle) *triangle = -1;
   ray_scene_hit(ray, scene, hit, triangle);
+}
+
+void oracle_trace_rays(Scene const *scene, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv) {
+  for (i32 i = 0; i < n; i++) {
+    Ray r;
+    r.position.x = rays[i * 6 + 0]; r.position.y = rays[i * 6 + 1]; r.position.z = rays[i * 6 + 2];
+    r.direction.x = rays[i * 6 + 3]; r.direction.y = rays[i * 6 + 4]; r.direction.z = rays[i * 6 + 5];
+    Hit hit;
+    memset(&hit, 0, sizeof hit);
+    hit.distance = RT_INF;
+    i32 tri = -1;
+    ray_scene_hit(&r, scene, &hit, &tri);
+    out_t[i] = hit.distance;
+    out_tri[i] = tri;
+    out_uv[i * 2 + 0] = (tri >= 0) ? tl_bary_u : 0.0f;
+    out_uv[i * 2 + 1] = (tri >= 0) ? tl_bary_v : 0.0f;
+  }
 }
 
 void oracle_sample_texture_bilinear(Image const *texture, f32 u, f32 v, f32 rgb[3]) {

@@ -16,6 +16,36 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.
+
+    librt_hip.so needs `libamdhip64.so.7`; PyTorch-ROCm ships its own copy of that library and
+    loads it by the unversioned name, so whichever is mapped first must serve both (two HSA
+    runtimes in one process cannot both own the GPU: the second reports "No HIP GPUs").
+    When torch is installed, map ITS copy first -- the multi-GPU launcher and the tests share
+    device buffers with torch.  RT_HIP_RUNTIME=system keeps the ROCm installation's runtime
+    (for processes that never import torch).
+    """
+    import importlib.util
+    import sys
+    if os.environ.get("RT_HIP_RUNTIME", "torch") != "torch":
+        return
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 class _Lazy:
     """Resolves the shared library on first attribute access."""
 
@@ -29,6 +59,7 @@ class _Lazy:
             raise NativeLibraryMissing(
                 f"{LIB_PATH} not found: build it with `make -C raytracing_c_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback for the render path")
+        _preload_hip_runtime()
         dll = C.CDLL(LIB_PATH)
         _declare(dll)
         self._dll = dll
