@@ -103,6 +103,7 @@ def main():
     import raytracing_c_amd as rt
     from raytracing_c_amd import ctypes_abi as abi
     from raytracing_c_amd.configs import load_config
+    from raytracing_c_amd.multi_gpu import FramePartition, gather_tiles
 
     torch.cuda.set_device(local_rank)
     if rt.lib.rt_init(local_rank) != 0:
@@ -130,15 +131,13 @@ def main():
         raise RuntimeError("rt_scene_upload: " + rt.last_error())
 
     dev = torch.device("cuda", local_rank)
-    n_chunks = rt.lib.rt_chunk_count(w, h)
-    max_local = (n_chunks + world - 1) // world
+    max_local = FramePartition(w, h, world).max_local
     accum = torch.zeros((h, w, 3), dtype=torch.int64, device=dev)
     image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
     tiles = torch.zeros((max_local, 1024 * 3), dtype=torch.uint8, device=dev)
     all_tiles = torch.zeros((world, max_local, 1024 * 3), dtype=torch.uint8, device=dev) if world > 1 else None
     host_image = torch.zeros((h, w, 3), dtype=torch.uint8).pin_memory()
     params = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, rank, world, args.slab, 0)
-    kernel_ms = []
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -152,7 +151,7 @@ def main():
             if rt.lib.rt_resolve(C.byref(params), accum.data_ptr(), tiles.data_ptr(), None, None, stream) != 0:
                 raise RuntimeError(rt.last_error())
             # framebuffer tiles of every rank -> every rank (RCCL all-gather over xGMI, 6 MB in total)
-            dist.all_gather_into_tensor(all_tiles.view(-1), tiles.view(-1))
+            gather_tiles(tiles, all_tiles)
             if rank == 0:
                 if rt.lib.rt_untile(w, h, world, all_tiles.data_ptr(), image.data_ptr(), stream) != 0:
                     raise RuntimeError(rt.last_error())
@@ -168,15 +167,17 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    rt.lib.rt_kernel_timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(None)     # placeholder; event time read after the region
     sync()
     elapsed = time.perf_counter() - t0
 
-    # per-launch kernel time from HIP events on the launch stream (last launch) and counters
-    last_ms = float(rt.lib.rt_last_kernel_ms())
+    # mean path-kernel time per launch over the timed region (HIP events recorded on the launch
+    # stream around every launch) and the in-kernel counters of the last frame
+    n_launches = C.c_int32(0)
+    last_ms = float(rt.lib.rt_kernel_timing_mean_ms(C.byref(n_launches)))
     cnt = rt.render.get_counters()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     stats = torch.tensor([cnt.paths, cnt.rays, cnt.node_visits, cnt.leaf_visits, cnt.shades, cnt.backgrounds,

@@ -119,6 +119,12 @@ extern int rt_get_counters(RT_Counters *out);
  * (HIP events on the launch stream); negative if none.  Synchronises. */
 extern f32 rt_last_kernel_ms(void);
 
+/* Mean GPU time per path-kernel launch over the launches since
+ * rt_kernel_timing_reset() (at most the last 256); *n_launches (optional)
+ * receives how many were averaged.  Synchronises. */
+extern void rt_kernel_timing_reset(void);
+extern f32  rt_kernel_timing_mean_ms(i32 *n_launches);
+
 /* ---- unit-level device entry points (parity tests call the same device
  * functions the render kernel uses) ------------------------------------------ */
 

@@ -83,9 +83,11 @@ struct Workspace {
   uint8_t            *image = nullptr;
   float              *linear = nullptr;
   size_t              image_pixels = 0;
-  hipEvent_t          ev0 = nullptr, ev1 = nullptr;
-  bool                timed = false;
+  // HIP event pairs around every path-kernel launch since the last timing reset
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t              n_timed = 0;
 };
+#define RT_MAX_TIMED 256
 static Workspace g_ws;
 
 static int ensure_device() {
@@ -103,8 +105,6 @@ static int ensure_device() {
   g_num_cus = prop.multiProcessorCount;
   HIP_TRY(hipMalloc(&g_ws.counters, RT_N_COUNTERS * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(&g_ws.work_head, 64));
-  HIP_TRY(hipEventCreate(&g_ws.ev0));
-  HIP_TRY(hipEventCreate(&g_ws.ev1));
   g_device_ready = true;
   return 0;
 }
@@ -475,11 +475,19 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     if (v > 0) max_blocks = g_num_cus * v;
   }
   if (blocks > max_blocks) blocks = max_blocks;
-  HIP_TRY(hipEventRecord(g_ws.ev0, stream));
+  size_t slot = g_ws.n_timed % RT_MAX_TIMED;
+  if (slot >= g_ws.ev0.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    g_ws.ev0.push_back(a);
+    g_ws.ev1.push_back(b);
+  }
+  HIP_TRY(hipEventRecord(g_ws.ev0[slot], stream));
   int rc = rt_launch_path_kernel(&K, blocks, stream);
   if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-  HIP_TRY(hipEventRecord(g_ws.ev1, stream));
-  g_ws.timed = true;
+  HIP_TRY(hipEventRecord(g_ws.ev1[slot], stream));
+  g_ws.n_timed += 1;
   return 0;
 }
 
@@ -615,13 +623,36 @@ extern "C" int rt_get_counters(RT_Counters *out) {
   return 0;
 }
 
+static float timed_slot_ms(size_t slot) {
+  if (hipEventSynchronize(g_ws.ev1[slot]) != hipSuccess) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventElapsedTime(&ms, g_ws.ev0[slot], g_ws.ev1[slot]) != hipSuccess) return -1.0f;
+  return ms;
+}
+
 extern "C" f32 rt_last_kernel_ms(void) {
   std::lock_guard<std::mutex> lock(g_mutex);
-  if (!g_device_ready || !g_ws.timed) return -1.0f;
-  if (hipEventSynchronize(g_ws.ev1) != hipSuccess) return -1.0f;
-  float ms = -1.0f;
-  if (hipEventElapsedTime(&ms, g_ws.ev0, g_ws.ev1) != hipSuccess) return -1.0f;
-  return ms;
+  if (!g_device_ready || g_ws.n_timed == 0) return -1.0f;
+  return timed_slot_ms((g_ws.n_timed - 1) % RT_MAX_TIMED);
+}
+
+extern "C" void rt_kernel_timing_reset(void) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  g_ws.n_timed = 0;
+}
+
+extern "C" f32 rt_kernel_timing_mean_ms(i32 *n_launches) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  size_t n = g_ws.n_timed < RT_MAX_TIMED ? g_ws.n_timed : RT_MAX_TIMED;
+  if (n_launches) *n_launches = (i32)n;
+  if (!g_device_ready || n == 0) return -1.0f;
+  double sum = 0.0;
+  for (size_t i = 0; i < n; i++) {
+    float ms = timed_slot_ms(i);
+    if (ms < 0.0f) return -1.0f;
+    sum += ms;
+  }
+  return (float)(sum / (double)n);
 }
 
 // ---------------------------------------------------------------------------------

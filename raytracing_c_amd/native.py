@@ -99,6 +99,9 @@ def _declare(d):
     d.rt_render_frame.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, vp, vp]
     d.rt_get_counters.argtypes = [P(abi.RT_Counters)]
     d.rt_last_kernel_ms.restype = C.c_float
+    d.rt_kernel_timing_reset.restype = None
+    d.rt_kernel_timing_mean_ms.argtypes = [P(C.c_int32)]
+    d.rt_kernel_timing_mean_ms.restype = C.c_float
     d.rt_test_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
     d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
