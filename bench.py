@@ -86,6 +86,22 @@ def cpu_baseline(hs, cfg, target_seconds):
             "msample_per_s": w * h * spp / dt / 1e6}
 
 
+def measured_traffic(workload):
+    """HBM bytes per rt_path_kernel launch from the newest committed PMC summary of this workload
+    (profiles/*_traffic.json, written by tools/summarize_profile.py from separate rocprofv3 --pmc
+    passes of this same command).  bench.py cannot read PMC counters itself."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == workload:
+            best = (t, os.path.basename(f))
+    return best
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,11 +217,13 @@ def main():
         # launches one kernel on its share of the chunks, the slowest rank's time is used.
         rays_per_launch = rays / world
         achieved = rays_per_launch * b_ray / (last_ms * 1e-3) / 1e9 if last_ms > 0 else None
+        workload = f"{cfg['asset']} {w}x{h}, {s} spp, {b} bounces (BASELINE.json configs[2])"
+        traffic = measured_traffic(workload) if world == 1 else None
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg['asset']} {w}x{h}, {s} spp, {b} bounces (BASELINE.json configs[2])",
+            "config": {"workload": workload,
                        "scene": "assets/helmet.glb = self-contained models/helmet.gltf; procedural 2048x1024 "
                                 "equirect background (background.png is a missing blob); seed 0x1234ABCD",
                        "partition": f"32x32 chunks interleaved over {world} GPU(s), RCCL all-gather of u8 tiles"
@@ -219,10 +237,16 @@ def main():
             "shades_per_ray": tot.shades / max(rays, 1),
             "kernel_ms": last_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
+                         "traffic_source": f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           "separate passes; 2 x FETCH_SIZE + WRITE_SIZE, x 1024)" if traffic else None,
+                         "kernel": "rt_path_kernel", "launches_averaged": int(n_launches.value),
+                         "algorithmic_bytes_per_launch": rays_per_launch * b_ray,
                          "bytes_per_ray": b_ray,
-                         "note": "algorithmic scene bytes (192 N + 288 L + 112 H + 48 X + 12 M per ray); "
-                                 "the 60 MB scene is cache resident, HBM traffic: see profiles/"},
+                         "note": "achieved = algorithmic scene bytes (192 N + 288 L + 112 H + 48 X + 12 M per ray, "
+                                 "counters from the kernel) / mean launch time; the 60 MB scene is cache "
+                                 "resident, so measured HBM traffic is ~1.5 % of the algorithmic bytes"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)
