@@ -442,7 +442,7 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   K->rank = p->rank;
   K->world = p->world;
   K->n_local_chunks = rt_local_chunk_count(p->width, p->height, p->rank, p->world);
-  int slab = p->slab > 0 ? p->slab : 64;
+  int slab = p->slab > 0 ? p->slab : 16;
   int shift = 0;
   while ((1 << shift) < slab && (1 << shift) < p->samples) shift++;
   K->slab_shift = shift;

@@ -46,6 +46,7 @@
 struct Ray3 {
   rt_v3 o, d;
   float inv_x, inv_y, inv_z;
+  bool  fast;     // origin and reciprocal direction all finite: NaN-free slab arithmetic
 };
 
 struct HitRec {
@@ -66,27 +67,55 @@ __device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
 __device__ __forceinline__ int   as_i(float f) { return __float_as_int(f); }
 
 // ---------------------------------------------------------------------------------
-// slab test of one child box, operand order of raytracer.c:209-228
+// Slab tests.  Two code paths with identical results wherever both are defined:
+//  * EXACT reproduces the operand order and the NaN behaviour of _mm256_min_ps /
+//    _mm256_max_ps in raytracer.c:209-228 with compare+select;
+//  * FAST uses v_min_f32 / v_max3_f32.  It is taken only for rays whose origin and
+//    reciprocal direction are all finite (Ray3::fast): then no NaN can appear in
+//    the slab arithmetic, and on NaN-free operands min/max are plain min/max, so
+//    both paths return the same bits (sign of zero cannot matter: every distance
+//    is clamped to >= EPSILON before it is used).  Axis-aligned rays (0 * inf)
+//    take the EXACT path; tests/test_gpu_parity.py sends such rays.
+
+__device__ __forceinline__ float fmin_hw(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float fmax_hw(float a, float b) { return __builtin_fmaxf(a, b); }
+
+template <bool FAST>
 __device__ __forceinline__ float slab_entry(const Ray3 &r, float mnx, float mny, float mnz,
                                             float mxx, float mxy, float mxz, float t_max) {
   float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
   float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
   float t0z = (mnz - r.o.z) * r.inv_z, t1z = (mxz - r.o.z) * r.inv_z;
-  float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
-  float bx = rt_max_ps(t0x, t1x), by = rt_max_ps(t0y, t1y), bz = rt_max_ps(t0z, t1z);
-  float t_minv = rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
-  float t_maxv = rt_min_ps(t_max, rt_min_ps(bx, rt_min_ps(by, bz)));
-  return (t_minv >= t_maxv) ? RT_INF : t_minv;
+  if (FAST) {
+    float sx = fmin_hw(t0x, t1x), sy = fmin_hw(t0y, t1y), sz = fmin_hw(t0z, t1z);
+    float bx = fmax_hw(t0x, t1x), by = fmax_hw(t0y, t1y), bz = fmax_hw(t0z, t1z);
+    float t_minv = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+    float t_maxv = fmin_hw(t_max, fmin_hw(bx, fmin_hw(by, bz)));
+    // t_maxv <= t_max, so "entry < exit" already implies the candidate test entry < t_max
+    return (t_minv < t_maxv) ? t_minv : RT_INF;
+  } else {
+    float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
+    float bx = rt_max_ps(t0x, t1x), by = rt_max_ps(t0y, t1y), bz = rt_max_ps(t0z, t1z);
+    float t_minv = rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
+    float t_maxv = rt_min_ps(t_max, rt_min_ps(bx, rt_min_ps(by, bz)));
+    float e = (t_minv >= t_maxv) ? RT_INF : t_minv;
+    return (e < t_max) ? e : RT_INF;       // candidate test of raytracer.c:464
+  }
 }
 
 // Entry distance of child j only; the miss test against t_max was already passed
 // when the node was entered, so only t_minv is needed (see header comment).
+template <bool FAST>
 __device__ __forceinline__ float slab_entry_child(const RT_KParams &P, const Ray3 &r, int node, int j) {
   const float *n = P.nodes + (size_t)node * 48 + j;
   float mnx = n[0], mny = n[8], mnz = n[16], mxx = n[24], mxy = n[32], mxz = n[40];
   float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
   float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
   float t0z = (mnz - r.o.z) * r.inv_z, t1z = (mxz - r.o.z) * r.inv_z;
+  if (FAST) {
+    float sx = fmin_hw(t0x, t1x), sy = fmin_hw(t0y, t1y), sz = fmin_hw(t0z, t1z);
+    return fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+  }
   float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
   return rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
 }
@@ -94,45 +123,46 @@ __device__ __forceinline__ float slab_entry_child(const RT_KParams &P, const Ray
 // Tests the 8 children of `node` against the ray with t_max = hit_t and returns
 // the near-first visiting order of the children that can still matter:
 //   bits 0..23  child indices, nearest first (ties: lowest index first)
-//   bits 24..27 how many
+//   bits 24..27 how many of them are candidates (entry < hit_t)
 // This is the selection loop of raytracer.c:459-468 done once, as a rank sort.
+// Candidate distances are positive floats or +inf, so they order like their bit
+// patterns: rank arithmetic runs on integers (sign bit of a difference), without
+// compare/select pairs.  Non-candidates (+inf) rank behind every candidate, so
+// the 8 ranks are a permutation and the word needs no per-child condition.
+template <bool FAST>
 __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t) {
   const float *nb = P.nodes + (size_t)node * 48;
-  float4 a;
-  float mnx[8], mny[8], mnz[8], mxx[8], mxy[8], mxz[8];
-#define LD8(dst, q)                                                       \
-  a = ld4(nb, (q));     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; \
-  a = ld4(nb, (q) + 1); dst[4] = a.x; dst[5] = a.y; dst[6] = a.z; dst[7] = a.w;
-  LD8(mnx, 0) LD8(mny, 2) LD8(mnz, 4) LD8(mxx, 6) LD8(mxy, 8) LD8(mxz, 10)
-#undef LD8
-
-  float d[8];
+  int d[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    float e = slab_entry(r, mnx[k], mny[k], mnz[k], mxx[k], mxy[k], mxz[k], hit_t);
-    d[k] = (e < hit_t) ? e : RT_INF;       // candidate test of raytracer.c:464
+  for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
+    float4 mnx = ld4(nb, 0 + h), mny = ld4(nb, 2 + h), mnz = ld4(nb, 4 + h);
+    float4 mxx = ld4(nb, 6 + h), mxy = ld4(nb, 8 + h), mxz = ld4(nb, 10 + h);
+    d[h * 4 + 0] = as_i(slab_entry<FAST>(r, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, hit_t));
+    d[h * 4 + 1] = as_i(slab_entry<FAST>(r, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, hit_t));
+    d[h * 4 + 2] = as_i(slab_entry<FAST>(r, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, hit_t));
+    d[h * 4 + 3] = as_i(slab_entry<FAST>(r, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, hit_t));
   }
 
+  // rank[k] starts at k (the pairs (j,k), j<k, it loses by default) and moves by the sign bits
   int rank[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) rank[k] = 0;
+  for (int k = 0; k < 8; k++) rank[k] = k;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
 #pragma unroll
     for (int k = j + 1; k < 8; k++) {
-      int kb = d[k] < d[j];
+      int kb = (int)((uint32_t)(d[k] - d[j]) >> 31);      // 1 iff d[k] < d[j]
       rank[j] += kb;
-      rank[k] += 1 - kb;
+      rank[k] -= kb;
     }
   }
-  uint32_t w = 0, cnt = 0;
+  uint32_t w = 0, n_inf = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    bool c = d[j] < RT_INF;
-    w |= c ? ((uint32_t)j << (3 * rank[j])) : 0u;
-    cnt += c ? 1u : 0u;
+    w |= (uint32_t)j << (3 * rank[j]);
+    n_inf += ((uint32_t)d[j] + 0x00800000u) >> 31;          // 1 iff d[j] == +inf
   }
-  return w | (cnt << 24);
+  return w | ((8u - n_inf) << 24);
 }
 
 // 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32)
@@ -179,6 +209,7 @@ __device__ __forceinline__ bool leaf_test(const RT_KParams &P, const Ray3 &r, in
 
 // Closest hit along r (raytracer.c:497-503 -> :443-483).  perm = this wave's
 // LDS perm-stack, indexed [level*64 + lane].
+template <bool FAST>
 __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, HitRec &hit,
                                           uint32_t *perm, int lane, LaneCounters &cn) {
   hit.t = RT_INF;
@@ -195,7 +226,7 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
   int      level = 0, node = 0;
   uint32_t dirty = 0;
   cn.nodes += 1;
-  uint32_t cur = node_enter(P, r, 0, hit.t);
+  uint32_t cur = node_enter<FAST>(P, r, 0, hit.t);
 
   while (level >= 0) {
     uint32_t cnt = cur >> 24;
@@ -210,7 +241,7 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
       cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
       bool go = true;
       if ((dirty >> level) & 1u) {
-        float dj = slab_entry_child(P, r, node, j);
+        float dj = slab_entry_child<FAST>(P, r, node, j);
         if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
       }
       if (go) {
@@ -228,7 +259,7 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
       node = child;
       level += 1;
       cn.nodes += 1;
-      cur = node_enter(P, r, node, hit.t);
+      cur = node_enter<FAST>(P, r, node, hit.t);
       dirty &= ~(1u << level);
     }
   }
@@ -502,6 +533,8 @@ __device__ __forceinline__ void ray_setup(Ray3 &r, rt_v3 o, rt_v3 d) {
   r.inv_x = 1.0f / d.x;       // raytracer.c:198-202
   r.inv_y = 1.0f / d.y;
   r.inv_z = 1.0f / d.z;
+  r.fast = (rt_absf(r.inv_x) < RT_INF) && (rt_absf(r.inv_y) < RT_INF) && (rt_absf(r.inv_z) < RT_INF) &&
+           (rt_absf(o.x) < RT_INF) && (rt_absf(o.y) < RT_INF) && (rt_absf(o.z) < RT_INF);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -591,7 +624,12 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
       hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
       Ray3 ray;
       ray_setup(ray, org, dir);
-      if (alive) trace_ray(P, ray, hit, perm, lane, cn);
+      // wave-uniform choice of the slab code path (see "Slab tests" above)
+      if (__all(!alive || ray.fast)) {
+        if (alive) trace_ray<true>(P, ray, hit, perm, lane, cn);
+      } else {
+        if (alive) trace_ray<false>(P, ray, hit, perm, lane, cn);
+      }
 
       // ---- shade / environment ----
       bool  done = false;
@@ -771,7 +809,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_test_trace_kernel(RT_KPar
   ray_setup(r, rt_v3_make(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]),
             rt_v3_make(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]));
   HitRec hit;
-  trace_ray(P, r, hit, s_perm[wave], lane, cn);
+  if (r.fast) trace_ray<true>(P, r, hit, s_perm[wave], lane, cn);
+  else trace_ray<false>(P, r, hit, s_perm[wave], lane, cn);
   out_t[i] = hit.t;
   out_tri[i] = hit.tri;
   out_uv[i * 2 + 0] = hit.u;

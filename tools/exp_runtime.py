@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""GPU experiment helper: kernel time of one config under runtime knobs (slab size, blocks per CU).
+    python tools/exp_runtime.py [config] [--reps 3]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch                                           # noqa: E402
+import raytracing_c_amd as rt                          # noqa: E402
+from raytracing_c_amd import ctypes_abi as abi         # noqa: E402
+from raytracing_c_amd.configs import load_config       # noqa: E402
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "helmet"
+    reps = 3
+    assert rt.lib.rt_init(0) == 0
+    hs, cfg = load_config(name)
+    w, h, s, b = cfg["width"], cfg["height"], cfg["samples"], cfg["max_bounces"]
+    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    accum = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda")
+
+    def run(slab, bpc):
+        os.environ["RT_BLOCKS_PER_CU"] = str(bpc)
+        p = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, 0, 1, slab, 0)
+        rt.lib.rt_kernel_timing_reset()
+        for _ in range(reps):
+            accum.zero_()
+            assert rt.lib.rt_render_accumulate(d, C.byref(p), accum.data_ptr(), None) == 0, rt.last_error()
+        torch.cuda.synchronize()
+        n = C.c_int32()
+        return rt.lib.rt_kernel_timing_mean_ms(C.byref(n))
+
+    run(64, 4)
+    knobs = os.environ.get("RT_EXP", "slab,bpc").split(",")
+    if "slab" in knobs:
+        for slab in (8, 16, 32, 64, 128, 256):
+            print(f"slab {slab:4d} bpc 4: {run(slab, 4):8.3f} ms", flush=True)
+    if "bpc" in knobs:
+        for bpc in (1, 2, 3, 4, 6, 8):
+            print(f"slab   64 bpc {bpc}: {run(64, bpc):8.3f} ms", flush=True)
+    c = rt.render.get_counters()
+    print("rays", c.rays, "Mray/s at last run n/a")
+
+
+if __name__ == "__main__":
+    main()
