@@ -20,7 +20,7 @@
 
 // launchers in rt_kernels.hip
 extern "C" {
-int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, hipStream_t stream);
+int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, int variant, hipStream_t stream);
 int rt_launch_resolve(int width, int height, int samples, int chunks_x, int rank, int world, int n_local_chunks,
                       const unsigned long long *accum, uint8_t *tiles, uint8_t *image, float *linear,
                       hipStream_t stream);
@@ -484,7 +484,16 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     g_ws.ev1.push_back(b);
   }
   HIP_TRY(hipEventRecord(g_ws.ev0[slot], stream));
-  int rc = rt_launch_path_kernel(&K, blocks, stream);
+  int variant = 2;                          // 1 = plain while-while kernel, 2 = phase-scheduled kernel
+  if (const char *e = getenv("RT_KERNEL")) variant = atoi(e);
+  K.sample_major = 0;
+  if (const char *e = getenv("RT_SAMPLE_MAJOR")) K.sample_major = atoi(e) != 0;
+  K.sched_thresh = 48;
+  if (const char *e = getenv("RT_SCHED_THRESH")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 64) K.sched_thresh = v;
+  }
+  int rc = rt_launch_path_kernel(&K, blocks, variant, stream);
   if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_TRY(hipEventRecord(g_ws.ev1[slot], stream));
   g_ws.n_timed += 1;

@@ -77,6 +77,8 @@ typedef struct {
   int32_t slab_shift;          /* samples per work item = 1 << slab_shift */
   int32_t n_slabs;             /* ceil(samples / slab)                    */
   int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
+  int32_t sched_thresh;        /* lanes waiting for shade/regenerate that trigger it */
+  int32_t sample_major;        /* work-item index -> (pixel, sample) mapping         */
   /* outputs */
   unsigned long long *accum;   /* [height*width*3] 32.32 fixed point      */
   unsigned long long *counters;/* RT_N_COUNTERS                           */

@@ -63,6 +63,12 @@ __device__ __forceinline__ float4 ld4(const float *base, int idx4) {
   return reinterpret_cast<const float4 *>(base)[idx4];
 }
 
+// Wave-uniform reads go through the scalar cache: a pointer in the constant address space with a
+// uniform (SGPR) address makes hipcc emit s_load_dwordx16 instead of one vector load per lane --
+// no L1/TD return traffic and no VGPRs for the node or leaf data.
+typedef const float __attribute__((address_space(4))) cfloat;
+__device__ __forceinline__ cfloat *as_scalar_ptr(const float *p) { return (cfloat *)(unsigned long long)p; }
+
 __device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
 __device__ __forceinline__ int   as_i(float f) { return __float_as_int(f); }
 
@@ -129,18 +135,26 @@ __device__ __forceinline__ float slab_entry_child(const RT_KParams &P, const Ray
 // patterns: rank arithmetic runs on integers (sign bit of a difference), without
 // compare/select pairs.  Non-candidates (+inf) rank behind every candidate, so
 // the 8 ranks are a permutation and the word needs no per-child condition.
-template <bool FAST>
+template <bool FAST, bool SCALAR>
 __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t) {
-  const float *nb = P.nodes + (size_t)node * 48;
   int d[8];
+  if (SCALAR) {                            // `node` is wave-uniform: node data lives in SGPRs
+    cfloat *nb = as_scalar_ptr(P.nodes) + (size_t)node * 48;
 #pragma unroll
-  for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
-    float4 mnx = ld4(nb, 0 + h), mny = ld4(nb, 2 + h), mnz = ld4(nb, 4 + h);
-    float4 mxx = ld4(nb, 6 + h), mxy = ld4(nb, 8 + h), mxz = ld4(nb, 10 + h);
-    d[h * 4 + 0] = as_i(slab_entry<FAST>(r, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, hit_t));
-    d[h * 4 + 1] = as_i(slab_entry<FAST>(r, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, hit_t));
-    d[h * 4 + 2] = as_i(slab_entry<FAST>(r, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, hit_t));
-    d[h * 4 + 3] = as_i(slab_entry<FAST>(r, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, hit_t));
+    for (int k = 0; k < 8; k++) {
+      d[k] = as_i(slab_entry<FAST>(r, nb[k], nb[8 + k], nb[16 + k], nb[24 + k], nb[32 + k], nb[40 + k], hit_t));
+    }
+  } else {
+    const float *nb = P.nodes + (size_t)node * 48;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
+      float4 mnx = ld4(nb, 0 + h), mny = ld4(nb, 2 + h), mnz = ld4(nb, 4 + h);
+      float4 mxx = ld4(nb, 6 + h), mxy = ld4(nb, 8 + h), mxz = ld4(nb, 10 + h);
+      d[h * 4 + 0] = as_i(slab_entry<FAST>(r, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, hit_t));
+      d[h * 4 + 1] = as_i(slab_entry<FAST>(r, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, hit_t));
+      d[h * 4 + 2] = as_i(slab_entry<FAST>(r, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, hit_t));
+      d[h * 4 + 3] = as_i(slab_entry<FAST>(r, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, hit_t));
+    }
   }
 
   // rank[k] starts at k (the pairs (j,k), j<k, it loses by default) and moves by the sign bits
@@ -165,36 +179,57 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
   return w | ((8u - n_inf) << 24);
 }
 
-// 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32)
+// 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32).
+// One triangle: Moeller-Trumbore without determinant test; returns the sanitised distance.
+__device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, float az, float bx, float by, float bz,
+                                          float cx, float cy, float cz, float &u_out, float &v_out) {
+  rt_v3 a = rt_v3_make(ax, ay, az);
+  rt_v3 edge1 = rt_v3_sub(rt_v3_make(bx, by, bz), a);
+  rt_v3 edge2 = rt_v3_sub(rt_v3_make(cx, cy, cz), a);
+  rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
+  float det = rt_v3_dot(edge1, rxe2);
+  float inv_det = 1.0f / det;
+  rt_v3 s = rt_v3_sub(r.o, a);
+  rt_v3 sxe1 = rt_v3_cross(s, edge1);
+  float u = inv_det * rt_v3_dot(s, rxe2);
+  float v = inv_det * rt_v3_dot(r.d, sxe1);
+  float t = inv_det * rt_v3_dot(edge2, sxe1);
+  bool miss = (u < -RT_EPS) || (u > 1.0f + RT_EPS) || (v < -RT_EPS) || (u + v > 1.0f + RT_EPS) || (t < RT_EPS);
+  float dist = miss ? RT_INF : t;
+  u_out = u;
+  v_out = v;
+  return (dist > 0.0f) ? dist : RT_INF;          // NaN -> +inf (min_f32x8)
+}
+
+template <bool SCALAR>
 __device__ __forceinline__ bool leaf_test(const RT_KParams &P, const Ray3 &r, int g, HitRec &hit) {
-  const float *lb = P.leaves + (size_t)g * 72;
   float best = RT_INF, bu = 0.0f, bv = 0.0f;
   int   bi = 0;
+  if (SCALAR) {                            // `g` is wave-uniform: the 288-byte tile comes through SGPRs
+    cfloat *lb = as_scalar_ptr(P.leaves) + (size_t)g * 72;
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-    float4 x0 = ld4(lb, 0 + h), x1 = ld4(lb, 2 + h), x2 = ld4(lb, 4 + h);
-    float4 y0 = ld4(lb, 6 + h), y1 = ld4(lb, 8 + h), y2 = ld4(lb, 10 + h);
-    float4 z0 = ld4(lb, 12 + h), z1 = ld4(lb, 14 + h), z2 = ld4(lb, 16 + h);
-    float ax[4] = {x0.x, x0.y, x0.z, x0.w}, bx[4] = {x1.x, x1.y, x1.z, x1.w}, cx[4] = {x2.x, x2.y, x2.z, x2.w};
-    float ay[4] = {y0.x, y0.y, y0.z, y0.w}, by[4] = {y1.x, y1.y, y1.z, y1.w}, cy[4] = {y2.x, y2.y, y2.z, y2.w};
-    float az[4] = {z0.x, z0.y, z0.z, z0.w}, bz[4] = {z1.x, z1.y, z1.z, z1.w}, cz[4] = {z2.x, z2.y, z2.z, z2.w};
+    for (int k = 0; k < 8; k++) {
+      float u, v;
+      float dist = tri_test(r, lb[k], lb[24 + k], lb[48 + k], lb[8 + k], lb[32 + k], lb[56 + k],
+                            lb[16 + k], lb[40 + k], lb[64 + k], u, v);
+      if (dist < best) { best = dist; bi = k; bu = u; bv = v; }   // lowest lane wins ties
+    }
+  } else {
+    const float *lb = P.leaves + (size_t)g * 72;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      rt_v3 a = rt_v3_make(ax[k], ay[k], az[k]);
-      rt_v3 edge1 = rt_v3_sub(rt_v3_make(bx[k], by[k], bz[k]), a);
-      rt_v3 edge2 = rt_v3_sub(rt_v3_make(cx[k], cy[k], cz[k]), a);
-      rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
-      float det = rt_v3_dot(edge1, rxe2);
-      float inv_det = 1.0f / det;
-      rt_v3 s = rt_v3_sub(r.o, a);
-      rt_v3 sxe1 = rt_v3_cross(s, edge1);
-      float u = inv_det * rt_v3_dot(s, rxe2);
-      float v = inv_det * rt_v3_dot(r.d, sxe1);
-      float t = inv_det * rt_v3_dot(edge2, sxe1);
-      bool miss = (u < -RT_EPS) || (u > 1.0f + RT_EPS) || (v < -RT_EPS) || (u + v > 1.0f + RT_EPS) || (t < RT_EPS);
-      float dist = miss ? RT_INF : t;
-      dist = (dist > 0.0f) ? dist : RT_INF;          // NaN -> +inf (min_f32x8)
-      if (dist < best) { best = dist; bi = h * 4 + k; bu = u; bv = v; }   // lowest lane wins ties
+    for (int h = 0; h < 2; h++) {
+      float4 x0 = ld4(lb, 0 + h), x1 = ld4(lb, 2 + h), x2 = ld4(lb, 4 + h);
+      float4 y0 = ld4(lb, 6 + h), y1 = ld4(lb, 8 + h), y2 = ld4(lb, 10 + h);
+      float4 z0 = ld4(lb, 12 + h), z1 = ld4(lb, 14 + h), z2 = ld4(lb, 16 + h);
+      float ax[4] = {x0.x, x0.y, x0.z, x0.w}, bx[4] = {x1.x, x1.y, x1.z, x1.w}, cx[4] = {x2.x, x2.y, x2.z, x2.w};
+      float ay[4] = {y0.x, y0.y, y0.z, y0.w}, by[4] = {y1.x, y1.y, y1.z, y1.w}, cy[4] = {y2.x, y2.y, y2.z, y2.w};
+      float az[4] = {z0.x, z0.y, z0.z, z0.w}, bz[4] = {z1.x, z1.y, z1.z, z1.w}, cz[4] = {z2.x, z2.y, z2.z, z2.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float u, v;
+        float dist = tri_test(r, ax[k], ay[k], az[k], bx[k], by[k], bz[k], cx[k], cy[k], cz[k], u, v);
+        if (dist < best) { best = dist; bi = h * 4 + k; bu = u; bv = v; }   // lowest lane wins ties
+      }
     }
   }
   if (best < hit.t) {
@@ -219,14 +254,14 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
   cn.rays += 1;
   if (P.depth <= 0) {          // one leaf group, no nodes (rt_scene.h, depth-0 rule)
     cn.leaves += 1;
-    leaf_test(P, r, 0, hit);
+    leaf_test<true>(P, r, 0, hit);
     return;
   }
   const int leaf_level = P.depth - 1;
   int      level = 0, node = 0;
   uint32_t dirty = 0;
   cn.nodes += 1;
-  uint32_t cur = node_enter<FAST>(P, r, 0, hit.t);
+  uint32_t cur = node_enter<FAST, FAST>(P, r, 0, hit.t);     // the root is uniform by construction
 
   while (level >= 0) {
     uint32_t cnt = cur >> 24;
@@ -252,14 +287,21 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
     }
     if (do_leaf) {
       cn.leaves += 1;
-      if (leaf_test(P, r, child - P.last_row_offset, hit)) dirty = 0xFFFFFFFFu;
+      int  g = child - P.last_row_offset;
+      int  g0 = __builtin_amdgcn_readfirstlane(g);
+      bool got;
+      if (FAST && __ballot(g != g0) == 0) got = leaf_test<true>(P, r, g0, hit);    // all lanes on one leaf
+      else got = leaf_test<false>(P, r, g, hit);
+      if (got) dirty = 0xFFFFFFFFu;
     }
     if (do_enter) {
       perm[level * 64 + lane] = cur;
       node = child;
       level += 1;
       cn.nodes += 1;
-      cur = node_enter<FAST>(P, r, node, hit.t);
+      int n0 = __builtin_amdgcn_readfirstlane(node);
+      if (FAST && __ballot(node != n0) == 0) cur = node_enter<FAST, true>(P, r, n0, hit.t);   // all lanes on one node
+      else cur = node_enter<FAST, false>(P, r, node, hit.t);
       dirty &= ~(1u << level);
     }
   }
@@ -543,6 +585,59 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+// One accepted closest hit -> pass-through or material evaluation and the next ray of the path
+// (raytracer.c:515-552).  Returns true when the path ended (radiance holds its value).
+__device__ __forceinline__ bool shade_hit(const RT_KParams &P, const HitRec &hit, rt_v3 &org, rt_v3 &dir,
+                                          rt_v3 &tint, rt_v3 &emis, uint32_t &rng, int &bounce,
+                                          LaneCounters &cn, rt_v3 &radiance) {
+  bool done = false;
+  const float *tb = P.tris + (size_t)hit.tri * 28;
+  float4 q0 = ld4(tb, 0), q1 = ld4(tb, 1), q2 = ld4(tb, 2), q3 = ld4(tb, 3);
+  float4 q4 = ld4(tb, 4), q5 = ld4(tb, 5), q6 = ld4(tb, 6);
+  float t1 = hit.u, t2 = hit.v;
+  float t0 = 1.0f - t1 - t2;
+  rt_v3 point = rt_v3_add(org, rt_v3_scale(dir, hit.t));
+  rt_v3 n_geo = rt_v3_make(q0.x, q0.y, q0.z);
+  rt_v3 n_int = rt_v3_make(q1.x * t0 + q2.x * t1 + q3.x * t2,
+                           q1.y * t0 + q2.y * t1 + q3.y * t2,
+                           q1.z * t0 + q2.z * t1 + q3.z * t2);
+  if (rt_v3_dot(n_geo, dir) > 0.0f || rt_v3_dot(n_int, dir) > 0.0f) {
+    // back face: pass through, costs a bounce (raytracer.c:516-522)
+    org = rt_v3_add(point, rt_v3_scale(dir, RT_EPS));
+  } else {
+    ShadeIn in;
+    in.direction = dir;
+    in.normal = rt_v3_normalize(n_int);
+    in.tangent = rt_v3_make(q4.x, q4.y, q4.z);
+    in.bitangent = rt_v3_make(q5.x, q5.y, q5.z);
+    in.uvx = q1.w * t0 + q3.w * t1 + q5.w * t2;
+    in.uvy = q2.w * t0 + q4.w * t1 + q6.x * t2;
+    rt_v3 out_dir, s_tint, s_emis;
+    bool terminate;
+    cn.shades += 1;
+    shade(P, as_i(q0.w), in, rng, out_dir, s_tint, s_emis, terminate, cn);
+    emis = rt_v3_add(emis, rt_v3_mul(s_emis, tint));
+    if (terminate) {
+      done = true;
+      radiance = emis;
+    } else {
+      dir = out_dir;
+      tint = rt_v3_mul(tint, s_tint);
+      float below = (rt_v3_dot(n_geo, out_dir) < 0.0f) ? 1.0f : 0.0f;
+      float bias = (0.5f - below) * 2.0f * RT_EPS;
+      org = rt_v3_add(point, rt_v3_scale(n_geo, bias));
+    }
+  }
+  if (!done) {
+    bounce += 1;
+    if (bounce >= P.max_bounces) {     // bounces exhausted: emission only (raytracer.c:557)
+      done = true;
+      radiance = emis;
+    }
+  }
+  return done;
+}
+
 // ---------------------------------------------------------------------------------
 // The path-tracing kernel.  Persistent: the grid is sized to the machine, each
 // wave loops over work items until the head counter runs past n_work.
@@ -598,8 +693,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
           int my_k = next_k + (int)__popcll(need & ((1ull << lane) - 1ull));
           next_k += (int)__popcll(need);
           if (!alive && my_k < item_paths) {
-            int p = my_k >> P.slab_shift;
-            int s = s_base + (my_k & (slab - 1));
+            int p = P.sample_major ? (my_k & 63) : (my_k >> P.slab_shift);
+            int s = s_base + (P.sample_major ? (my_k >> 6) : (my_k & (slab - 1)));
             int x = tile_x0 + (p & 7), y = tile_y0 + (p >> 3);
             if (s < P.samples && x < P.width && y < P.height && P.max_bounces > 0) {
               alive = true;
@@ -636,50 +731,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
       rt_v3 radiance = rt_v3_make(0, 0, 0);
       if (alive) {
         if (hit.tri >= 0) {
-          const float *tb = P.tris + (size_t)hit.tri * 28;
-          float4 q0 = ld4(tb, 0), q1 = ld4(tb, 1), q2 = ld4(tb, 2), q3 = ld4(tb, 3);
-          float4 q4 = ld4(tb, 4), q5 = ld4(tb, 5), q6 = ld4(tb, 6);
-          float t1 = hit.u, t2 = hit.v;
-          float t0 = 1.0f - t1 - t2;
-          rt_v3 point = rt_v3_add(org, rt_v3_scale(dir, hit.t));
-          rt_v3 n_geo = rt_v3_make(q0.x, q0.y, q0.z);
-          rt_v3 n_int = rt_v3_make(q1.x * t0 + q2.x * t1 + q3.x * t2,
-                                   q1.y * t0 + q2.y * t1 + q3.y * t2,
-                                   q1.z * t0 + q2.z * t1 + q3.z * t2);
-          if (rt_v3_dot(n_geo, dir) > 0.0f || rt_v3_dot(n_int, dir) > 0.0f) {
-            // back face: pass through, costs a bounce (raytracer.c:516-522)
-            org = rt_v3_add(point, rt_v3_scale(dir, RT_EPS));
-          } else {
-            ShadeIn in;
-            in.direction = dir;
-            in.normal = rt_v3_normalize(n_int);
-            in.tangent = rt_v3_make(q4.x, q4.y, q4.z);
-            in.bitangent = rt_v3_make(q5.x, q5.y, q5.z);
-            in.uvx = q1.w * t0 + q3.w * t1 + q5.w * t2;
-            in.uvy = q2.w * t0 + q4.w * t1 + q6.x * t2;
-            rt_v3 out_dir, s_tint, s_emis;
-            bool terminate;
-            cn.shades += 1;
-            shade(P, as_i(q0.w), in, rng, out_dir, s_tint, s_emis, terminate, cn);
-            emis = rt_v3_add(emis, rt_v3_mul(s_emis, tint));
-            if (terminate) {
-              done = true;
-              radiance = emis;
-            } else {
-              dir = out_dir;
-              tint = rt_v3_mul(tint, s_tint);
-              float below = (rt_v3_dot(n_geo, out_dir) < 0.0f) ? 1.0f : 0.0f;
-              float bias = (0.5f - below) * 2.0f * RT_EPS;
-              org = rt_v3_add(point, rt_v3_scale(n_geo, bias));
-            }
-          }
-          if (!done) {
-            bounce += 1;
-            if (bounce >= P.max_bounces) {     // bounces exhausted: emission only (raytracer.c:557)
-              done = true;
-              radiance = emis;
-            }
-          }
+          done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
         } else {
           cn.bgs += 1;
           rt_v3 bg = background_lookup(P, dir);
@@ -712,6 +764,232 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
   }
 
   // ---- counters: one atomic per wave and counter ----
+  uint32_t c0 = wave_sum(cn.paths), c1 = wave_sum(cn.rays), c2 = wave_sum(cn.nodes), c3 = wave_sum(cn.leaves);
+  uint32_t c4 = wave_sum(cn.shades), c5 = wave_sum(cn.bgs), c6 = wave_sum(cn.textured);
+  if (lane == 0) {
+    atomicAdd(P.counters + CNT_PATHS, (unsigned long long)c0);
+    atomicAdd(P.counters + CNT_RAYS, (unsigned long long)c1);
+    atomicAdd(P.counters + CNT_NODES, (unsigned long long)c2);
+    atomicAdd(P.counters + CNT_LEAVES, (unsigned long long)c3);
+    atomicAdd(P.counters + CNT_SHADES, (unsigned long long)c4);
+    atomicAdd(P.counters + CNT_BG, (unsigned long long)c5);
+    atomicAdd(P.counters + CNT_TEXTURED, (unsigned long long)c6);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// The scheduled path kernel.  Same work items, same per-lane arithmetic as
+// rt_path_kernel, different control: every lane carries a phase and the wave picks, per
+// iteration, ONE block of code to run for all lanes that wait for it:
+//
+//   NODE  enter a BVH node (8 slab tests + rank sort)          \ the larger group of the two
+//   LEAF  test the 8 triangles of a leaf group                 /  runs, the other one waits
+//   S     shade hits, look up the environment for misses, start new camera paths --
+//         run when at least `sched_thresh` lanes wait for it (or nothing else is runnable)
+//
+// so a traversal that takes long no longer parks the lanes that already finished (they are
+// shaded / regenerated once enough of them wait), and node and leaf code each run on a dense
+// set of lanes instead of splitting every iteration between them.  Traversal state (level,
+// node, perm word, dirty mask, closest hit) simply persists in registers between blocks.
+#define PH_NEED 0     // no path: wants a new (pixel, sample)
+#define PH_POP  1     // traversal: take the next child of the current node (transient)
+#define PH_NODE 2     // traversal: wants node_enter(child)
+#define PH_LEAF 3     // traversal: wants leaf_test(child)
+#define PH_HIT  4     // traversal finished with a hit: wants shading
+#define PH_MISS 5     // traversal finished without a hit: wants the environment
+
+__global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel_sched(RT_KParams P) {
+  __shared__ uint32_t s_perm[RT_BLOCK_WAVES][RT_MAX_DEPTH * 64];
+  __shared__ unsigned long long s_acc[RT_BLOCK_WAVES][RT_TILE_PIX * 3];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t *perm = s_perm[wave];
+  unsigned long long *acc = s_acc[wave];
+
+  LaneCounters cn;
+  cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
+
+  acc[lane] = 0ull;
+  acc[lane + 64] = 0ull;
+  acc[lane + 128] = 0ull;
+
+  const int slab = 1 << P.slab_shift;
+  const int item_paths = RT_TILE_PIX << P.slab_shift;
+  const int leaf_level = P.depth - 1;
+  const int thresh = P.sched_thresh;
+
+  for (;;) {
+    // ---- dequeue one work item (wave-uniform).  Items are small (8x8 pixels x 16 samples by default):
+    //      measured, the frame time is set by how evenly the LAST items spread over the 4096 waves, not
+    //      by the bubble at the end of each item (keeping two items in flight per wave bought nothing
+    //      and cost 40 VGPRs) ----
+    uint32_t w = 0;
+    if (lane == 0) w = atomicAdd(P.work_head, 1u);
+    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    if (w >= (uint32_t)P.n_work) break;
+
+    const int slab_idx = (int)(w % (uint32_t)P.n_slabs);
+    const int tile_idx = (int)(w / (uint32_t)P.n_slabs);
+    const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
+    const int chunk = lchunk * P.world + P.rank;
+    const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
+    const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
+    if (tile_x0 >= P.width || tile_y0 >= P.height) continue;
+    const int s_base = slab_idx << P.slab_shift;
+
+    // ---- per-lane state ----
+    int   phase = PH_NEED;
+    int   pix = 0, bounce = 0;
+    uint32_t rng = 0;
+    Ray3  ray;
+    ray_setup(ray, rt_v3_make(0, 0, 0), rt_v3_make(0, 0, 1));
+    rt_v3 tint = rt_v3_make(1, 1, 1), emis = rt_v3_make(0, 0, 0);
+    int   level = -1, node = 0, child = 0;
+    uint32_t cur = 0, dirty = 0;
+    HitRec hit;
+    hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+    int next_k = 0;      // wave-uniform
+
+    for (;;) {
+      const bool can_regen = next_k < item_paths;
+      const int nN = (int)__popcll(__ballot(phase == PH_NODE));
+      const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
+      const int nS = (int)__popcll(__ballot(phase == PH_HIT || phase == PH_MISS || (can_regen && phase == PH_NEED)));
+      if (nN + nL + nS == 0) break;          // every lane idle and the item has no paths left
+
+      if (nS >= thresh || nN + nL == 0) {
+        // ================= S: shade, environment, regenerate =================
+        bool  done = false, start = false;
+        rt_v3 radiance = rt_v3_make(0, 0, 0);
+        rt_v3 org = ray.o, dir = ray.d;
+        if (phase == PH_HIT) {
+          done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
+          start = !done;
+        } else if (phase == PH_MISS) {
+          cn.bgs += 1;
+          rt_v3 bg = background_lookup(P, dir);
+          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
+          done = true;
+        }
+        if (done) {
+          atomicAdd(&acc[pix * 3 + 0], (unsigned long long)rt_accum_quantize(radiance.x));
+          atomicAdd(&acc[pix * 3 + 1], (unsigned long long)rt_accum_quantize(radiance.y));
+          atomicAdd(&acc[pix * 3 + 2], (unsigned long long)rt_accum_quantize(radiance.z));
+          phase = PH_NEED;
+        }
+        if (can_regen) {
+          unsigned long long need = __ballot(phase == PH_NEED);
+          if (need) {
+            int my_k = next_k + (int)__popcll(need & ((1ull << lane) - 1ull));
+            next_k += (int)__popcll(need);
+            if (phase == PH_NEED && my_k < item_paths) {
+              // k -> (pixel of the tile, sample of the slab): pixel-major keeps the lanes of a wave on one or
+              // two pixels, sample-major spreads them over the 64 pixels of the tile
+              int p = P.sample_major ? (my_k & 63) : (my_k >> P.slab_shift);
+              int s = s_base + (P.sample_major ? (my_k >> 6) : (my_k & (slab - 1)));
+              int x = tile_x0 + (p & 7), y = tile_y0 + (p >> 3);
+              if (s < P.samples && x < P.width && y < P.height && P.max_bounces > 0) {
+                pix = p;
+                bounce = 0;
+                rng = rt_path_seed(P.seed, (uint32_t)(x + y * P.width), (uint32_t)s);
+                primary_ray(P, x, y, s, org, dir);
+                tint = rt_v3_make(1, 1, 1);
+                emis = rt_v3_make(0, 0, 0);
+                cn.paths += 1;
+                start = true;
+              }
+            }
+          }
+        }
+        if (start) {                      // a new ray: traversal starts at the root (or at leaf group 0)
+          ray_setup(ray, org, dir);
+          hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+          cn.rays += 1;
+          dirty = 0;
+          cur = 0;
+          level = -1;
+          node = 0;
+          child = (P.depth > 0) ? 0 : P.last_row_offset;
+          phase = (P.depth > 0) ? PH_NODE : PH_LEAF;
+        }
+        continue;
+      }
+
+    if (nL >= nN) {
+        // ================= LEAF =================
+        if (phase == PH_LEAF) {
+          cn.leaves += 1;
+          int  g = child - P.last_row_offset;
+          int  g0 = __builtin_amdgcn_readfirstlane(g);
+          bool got;
+          if (__ballot(g != g0) == 0) got = leaf_test<true>(P, ray, g0, hit);     // all lanes on one leaf
+          else got = leaf_test<false>(P, ray, g, hit);
+          if (got) dirty = 0xFFFFFFFFu;
+          phase = PH_POP;
+        }
+      } else {
+        // ================= NODE =================
+        const bool all_fast = __ballot(phase == PH_NODE && !ray.fast) == 0;
+        if (phase == PH_NODE) {
+          if (level >= 0) perm[level * 64 + lane] = cur;
+          node = child;
+          level += 1;
+          cn.nodes += 1;
+          int n0 = __builtin_amdgcn_readfirstlane(node);
+          if (all_fast) {
+            if (__ballot(node != n0) == 0) cur = node_enter<true, true>(P, ray, n0, hit.t);   // all lanes on one node
+            else cur = node_enter<true, false>(P, ray, node, hit.t);
+          } else {
+            cur = node_enter<false, false>(P, ray, node, hit.t);
+          }
+          dirty &= ~(1u << level);
+          phase = PH_POP;
+        }
+      }
+
+      // ---- pops: cheap, run until every traversing lane wants a NODE, a LEAF or is finished ----
+      while (__any(phase == PH_POP)) {
+        if (phase == PH_POP) {
+          uint32_t cnt = cur >> 24;
+          if (cnt == 0 || level < 0) {
+            level -= 1;
+            node = (node - 1) >> 3;
+            if (level >= 0) cur = perm[level * 64 + lane];
+            else phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
+          } else {
+            int j = (int)(cur & 7u);
+            cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
+            bool go = true;
+            if ((dirty >> level) & 1u) {
+              float dj = slab_entry_child<false>(P, ray, node, j);
+              if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
+            }
+            if (go) {
+              child = 8 * node + 1 + j;
+              phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- flush the tile: lane p owns pixel p ----
+    {
+      int x = tile_x0 + (lane & 7), y = tile_y0 + (lane >> 3);
+      unsigned long long r = acc[lane * 3 + 0], g = acc[lane * 3 + 1], b = acc[lane * 3 + 2];
+      acc[lane * 3 + 0] = 0ull;
+      acc[lane * 3 + 1] = 0ull;
+      acc[lane * 3 + 2] = 0ull;
+      if (x < P.width && y < P.height) {
+        unsigned long long *dst = P.accum + ((size_t)y * P.width + x) * 3;
+        atomicAdd(dst + 0, r);
+        atomicAdd(dst + 1, g);
+        atomicAdd(dst + 2, b);
+      }
+    }
+  }
+
   uint32_t c0 = wave_sum(cn.paths), c1 = wave_sum(cn.rays), c2 = wave_sum(cn.nodes), c3 = wave_sum(cn.leaves);
   uint32_t c4 = wave_sum(cn.shades), c5 = wave_sum(cn.bgs), c6 = wave_sum(cn.textured);
   if (lane == 0) {
@@ -829,8 +1107,9 @@ __global__ void rt_test_texture_kernel(RT_KParams P, int tex, int n, const float
 // ---------------------------------------------------------------------------------
 // launchers (called from rt_api.cpp)
 
-extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(rt_path_kernel, dim3(n_blocks), dim3(RT_BLOCK_THREADS), 0, stream, *P);
+extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, int variant, hipStream_t stream) {
+  if (variant == 1) hipLaunchKernelGGL(rt_path_kernel, dim3(n_blocks), dim3(RT_BLOCK_THREADS), 0, stream, *P);
+  else hipLaunchKernelGGL(rt_path_kernel_sched, dim3(n_blocks), dim3(RT_BLOCK_THREADS), 0, stream, *P);
   return (int)hipGetLastError();
 }
 

@@ -35,6 +35,21 @@ def main():
 
     run(64, 4)
     knobs = os.environ.get("RT_EXP", "slab,bpc").split(",")
+    if "kernel" in knobs:
+        for kv in (1, 2):
+            os.environ["RT_KERNEL"] = str(kv)
+            for th in ((32,) if kv == 1 else (8, 16, 24, 32, 40, 48, 56, 64)):
+                os.environ["RT_SCHED_THRESH"] = str(th)
+                for slab in (16, 64):
+                    print(f"kernel {kv} thresh {th:2d} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
+        os.environ.pop("RT_KERNEL")
+        os.environ.pop("RT_SCHED_THRESH")
+    if "map" in knobs:
+        for sm in (0, 1):
+            os.environ["RT_SAMPLE_MAJOR"] = str(sm)
+            for slab in (4, 8, 16, 32, 64, 128, 256):
+                print(f"sample_major {sm} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
+        os.environ.pop("RT_SAMPLE_MAJOR")
     if "slab" in knobs:
         for slab in (8, 16, 32, 64, 128, 256):
             print(f"slab {slab:4d} bpc 4: {run(slab, 4):8.3f} ms", flush=True)
