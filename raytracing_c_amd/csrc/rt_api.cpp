@@ -20,7 +20,7 @@
 
 // launchers in rt_kernels.hip
 extern "C" {
-int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, int variant, hipStream_t stream);
+int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream);
 int rt_launch_resolve(int width, int height, int samples, int chunks_x, int rank, int world, int n_local_chunks,
                       const unsigned long long *accum, uint8_t *tiles, uint8_t *image, float *linear,
                       hipStream_t stream);
@@ -302,15 +302,24 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   }
   if (mats.empty()) mats.resize(20, 0.0f);
 
-  // leaf tiles: 9 rows x 8 per group
+  // leaf tiles: 9 rows x 8 per group: vertex a, then the edges b-a and c-a (raytracer.c:115-122 computes
+  // them per visit; the fp32 subtraction done here gives the same bits)
   const int n_groups = n / 8;
   std::vector<float> leaves((size_t)n_groups * 72);
   for (int g = 0; g < n_groups; g++) {
     float *l = &leaves[(size_t)g * 72];
-    for (int k = 0; k < 3; k++) {
-      memcpy(l + (0 + k) * 8, T.x[k] + g * 8, 32);
-      memcpy(l + (3 + k) * 8, T.y[k] + g * 8, 32);
-      memcpy(l + (6 + k) * 8, T.z[k] + g * 8, 32);
+    for (int k = 0; k < 8; k++) {
+      int i = g * 8 + k;
+      volatile float e;     // keep every difference a plain IEEE fp32 subtraction
+      l[0 * 8 + k] = T.x[0][i];
+      e = T.x[1][i] - T.x[0][i]; l[1 * 8 + k] = e;
+      e = T.x[2][i] - T.x[0][i]; l[2 * 8 + k] = e;
+      l[3 * 8 + k] = T.y[0][i];
+      e = T.y[1][i] - T.y[0][i]; l[4 * 8 + k] = e;
+      e = T.y[2][i] - T.y[0][i]; l[5 * 8 + k] = e;
+      l[6 * 8 + k] = T.z[0][i];
+      e = T.z[1][i] - T.z[0][i]; l[7 * 8 + k] = e;
+      e = T.z[2][i] - T.z[0][i]; l[8 * 8 + k] = e;
     }
   }
 
@@ -466,15 +475,42 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   HIP_TRY(hipMemsetAsync(g_ws.counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
   HIP_TRY(hipMemsetAsync(g_ws.work_head, 0, 64, stream));
   if (K.n_work == 0) return 0;
-  // persistent grid: enough waves to fill the machine, never more than the work
-  int waves = K.n_work;
-  int blocks = (waves + 3) / 4;
-  int max_blocks = g_num_cus * 4;            // 16 waves per CU
-  if (const char *e = getenv("RT_BLOCKS_PER_CU")) {
+  // persistent grid: 16 waves per CU (4 per SIMD at <= 128 VGPRs), never more waves than work items
+  int waves_per_cu = 16;
+  if (const char *e = getenv("RT_WAVES_PER_CU")) {
     int v = atoi(e);
-    if (v > 0) max_blocks = g_num_cus * v;
+    if (v > 0) waves_per_cu = v;
   }
-  if (blocks > max_blocks) blocks = max_blocks;
+  int n_waves = g_num_cus * waves_per_cu;
+  if (n_waves > K.n_work) n_waves = K.n_work;
+  int variant = 3;     // 1 plain while-while, 2 phase-scheduled, 3 phase-scheduled + top of the BVH in LDS
+  if (const char *e = getenv("RT_KERNEL")) variant = atoi(e);
+  K.sample_major = 0;
+  if (const char *e = getenv("RT_SAMPLE_MAJOR")) K.sample_major = atoi(e) != 0;
+  K.sched_thresh = 48;
+  if (const char *e = getenv("RT_SCHED_THRESH")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 64) K.sched_thresh = v;
+  }
+  // dynamic LDS per workgroup: per wave (perm stack: depth x 256 B, accumulator tile: 1536 B) and, for
+  // variant 3, as many leading BVH nodes (level order) as fit in the 160 KB of a CU at 208 B each
+  const int lds_limit = 160 * 1024;
+  int per_wave = (K.depth > 0 ? K.depth : 1) * 256 + 1536;
+  int smem = 0;
+  K.n_lds_nodes = 0;
+  if (variant == 2) {
+    smem = 4 * per_wave;
+  } else if (variant != 1) {
+    variant = 3;
+    int room = (lds_limit - 16 * per_wave) / 208;
+    if (room < 0) room = 0;
+    K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
+    if (const char *e = getenv("RT_LDS_NODES")) {
+      int v = atoi(e);
+      if (v >= 0 && v < K.n_lds_nodes) K.n_lds_nodes = v;
+    }
+    smem = K.n_lds_nodes * 208 + 16 * per_wave;
+  }
   size_t slot = g_ws.n_timed % RT_MAX_TIMED;
   if (slot >= g_ws.ev0.size()) {
     hipEvent_t a, b;
@@ -484,16 +520,7 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     g_ws.ev1.push_back(b);
   }
   HIP_TRY(hipEventRecord(g_ws.ev0[slot], stream));
-  int variant = 2;                          // 1 = plain while-while kernel, 2 = phase-scheduled kernel
-  if (const char *e = getenv("RT_KERNEL")) variant = atoi(e);
-  K.sample_major = 0;
-  if (const char *e = getenv("RT_SAMPLE_MAJOR")) K.sample_major = atoi(e) != 0;
-  K.sched_thresh = 48;
-  if (const char *e = getenv("RT_SCHED_THRESH")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= 64) K.sched_thresh = v;
-  }
-  int rc = rt_launch_path_kernel(&K, blocks, variant, stream);
+  int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, stream);
   if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   HIP_TRY(hipEventRecord(g_ws.ev1[slot], stream));
   g_ws.n_timed += 1;

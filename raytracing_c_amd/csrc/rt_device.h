@@ -3,9 +3,10 @@
  *
  * HBM layout (all read-only during a frame, 16-byte aligned):
  *   nodes   : BVH_Node as is, 12 float4 per node                 192 B / node
- *   leaves  : per leaf group g, 9 rows of 8 f32 (x0 x1 x2 y0 y1 y2 z0 z1 z2),
- *             i.e. the reference's nine SoA arrays (scene.h:53-63) re-tiled so
- *             one group is 288 contiguous bytes                   288 B / leaf
+ *   leaves  : per leaf group g, 9 rows of 8 f32 (ax e1x e2x ay e1y e2y az e1z e2z,
+ *             e1 = b-a, e2 = c-a): the reference's nine SoA arrays (scene.h:53-63)
+ *             re-tiled so one group is 288 contiguous bytes, with the two edge
+ *             subtractions of raytracer.c:115-122 done at upload  288 B / leaf
  *   tris    : Triangle_AOS without the Shader pair, plus a material id
  *                                                                 112 B / tri
  *   mats    : PBR_Shader_Data with texture pointers replaced by indices
@@ -79,6 +80,7 @@ typedef struct {
   int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
   int32_t sched_thresh;        /* lanes waiting for shade/regenerate that trigger it */
   int32_t sample_major;        /* work-item index -> (pixel, sample) mapping         */
+  int32_t n_lds_nodes;         /* BVH nodes [0, n) are also in the workgroup's LDS   */
   /* outputs */
   unsigned long long *accum;   /* [height*width*3] 32.32 fixed point      */
   unsigned long long *counters;/* RT_N_COUNTERS                           */

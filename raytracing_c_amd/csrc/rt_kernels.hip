@@ -112,8 +112,8 @@ __device__ __forceinline__ float slab_entry(const Ray3 &r, float mnx, float mny,
 // Entry distance of child j only; the miss test against t_max was already passed
 // when the node was entered, so only t_minv is needed (see header comment).
 template <bool FAST>
-__device__ __forceinline__ float slab_entry_child(const RT_KParams &P, const Ray3 &r, int node, int j) {
-  const float *n = P.nodes + (size_t)node * 48 + j;
+__device__ __forceinline__ float slab_entry_child(const float *n, const Ray3 &r) {
+  // n -> element j of the node's first row; the six rows are 8 floats apart
   float mnx = n[0], mny = n[8], mnz = n[16], mxx = n[24], mxy = n[32], mxz = n[40];
   float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
   float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
@@ -135,21 +135,28 @@ __device__ __forceinline__ float slab_entry_child(const RT_KParams &P, const Ray
 // patterns: rank arithmetic runs on integers (sign bit of a difference), without
 // compare/select pairs.  Non-candidates (+inf) rank behind every candidate, so
 // the 8 ranks are a permutation and the word needs no per-child condition.
-template <bool FAST, bool SCALAR>
-__device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t) {
+#define NODE_GLOBAL 0     // per-lane vector loads from HBM/L2/L1
+#define NODE_SCALAR 1     // wave-uniform node: s_load through the scalar cache
+#define NODE_LDS    2     // per-lane reads from the workgroup's LDS copy of the top of the tree
+#define RT_LDS_NODE_F4 13 // LDS node stride in float4 (12 data + 1 pad: 13 is odd, so random nodes spread over all 16-byte slots of a bank row)
+
+template <bool FAST, int MODE>
+__device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t,
+                                               const float4 *lds_nodes) {
   int d[8];
-  if (SCALAR) {                            // `node` is wave-uniform: node data lives in SGPRs
+  if (MODE == NODE_SCALAR) {               // `node` is wave-uniform: node data lives in SGPRs
     cfloat *nb = as_scalar_ptr(P.nodes) + (size_t)node * 48;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       d[k] = as_i(slab_entry<FAST>(r, nb[k], nb[8 + k], nb[16 + k], nb[24 + k], nb[32 + k], nb[40 + k], hit_t));
     }
   } else {
-    const float *nb = P.nodes + (size_t)node * 48;
+    const float4 *nb = (MODE == NODE_LDS) ? (lds_nodes + node * RT_LDS_NODE_F4)
+                                          : (reinterpret_cast<const float4 *>(P.nodes) + (size_t)node * 12);
 #pragma unroll
     for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
-      float4 mnx = ld4(nb, 0 + h), mny = ld4(nb, 2 + h), mnz = ld4(nb, 4 + h);
-      float4 mxx = ld4(nb, 6 + h), mxy = ld4(nb, 8 + h), mxz = ld4(nb, 10 + h);
+      float4 mnx = nb[0 + h], mny = nb[2 + h], mnz = nb[4 + h];
+      float4 mxx = nb[6 + h], mxy = nb[8 + h], mxz = nb[10 + h];
       d[h * 4 + 0] = as_i(slab_entry<FAST>(r, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, hit_t));
       d[h * 4 + 1] = as_i(slab_entry<FAST>(r, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, hit_t));
       d[h * 4 + 2] = as_i(slab_entry<FAST>(r, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, hit_t));
@@ -181,11 +188,13 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
 
 // 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32).
 // One triangle: Moeller-Trumbore without determinant test; returns the sanitised distance.
-__device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, float az, float bx, float by, float bz,
-                                          float cx, float cy, float cz, float &u_out, float &v_out) {
+__device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, float az, float e1x, float e1y, float e1z,
+                                          float e2x, float e2y, float e2z, float &u_out, float &v_out) {
+  // the leaf tile stores a, b-a, c-a: the two edge subtractions of raytracer.c:115-122 are done once
+  // at upload (same fp32 subtraction, same bits) instead of once per visit
   rt_v3 a = rt_v3_make(ax, ay, az);
-  rt_v3 edge1 = rt_v3_sub(rt_v3_make(bx, by, bz), a);
-  rt_v3 edge2 = rt_v3_sub(rt_v3_make(cx, cy, cz), a);
+  rt_v3 edge1 = rt_v3_make(e1x, e1y, e1z);
+  rt_v3 edge2 = rt_v3_make(e2x, e2y, e2z);
   rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
   float det = rt_v3_dot(edge1, rxe2);
   float inv_det = 1.0f / det;
@@ -261,7 +270,7 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
   int      level = 0, node = 0;
   uint32_t dirty = 0;
   cn.nodes += 1;
-  uint32_t cur = node_enter<FAST, FAST>(P, r, 0, hit.t);     // the root is uniform by construction
+  uint32_t cur = node_enter<FAST, FAST ? NODE_SCALAR : NODE_GLOBAL>(P, r, 0, hit.t, nullptr);     // the root is uniform by construction
 
   while (level >= 0) {
     uint32_t cnt = cur >> 24;
@@ -276,7 +285,7 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
       cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
       bool go = true;
       if ((dirty >> level) & 1u) {
-        float dj = slab_entry_child<FAST>(P, r, node, j);
+        float dj = slab_entry_child<FAST>(P.nodes + (size_t)node * 48 + j, r);
         if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
       }
       if (go) {
@@ -300,8 +309,8 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
       level += 1;
       cn.nodes += 1;
       int n0 = __builtin_amdgcn_readfirstlane(node);
-      if (FAST && __ballot(node != n0) == 0) cur = node_enter<FAST, true>(P, r, n0, hit.t);   // all lanes on one node
-      else cur = node_enter<FAST, false>(P, r, node, hit.t);
+      if (FAST && __ballot(node != n0) == 0) cur = node_enter<FAST, NODE_SCALAR>(P, r, n0, hit.t, nullptr);   // all lanes on one node
+      else cur = node_enter<FAST, NODE_GLOBAL>(P, r, node, hit.t, nullptr);
       dirty &= ~(1u << level);
     }
   }
@@ -309,9 +318,13 @@ __device__ __forceinline__ void trace_ray(const RT_KParams &P, const Ray3 &r, Hi
 
 // ---------------------------------------------------------------------------------
 // textures (driver.c:49-93); texels are RGBA8, alpha unused
+// u8 / 255.999f (driver.c:70-87) as a multiplication: i * RN(1/255.999f) equals RN(i / 255.999f)
+// for EVERY i in 0..255 (checked exhaustively in tests/test_oracle_kat.py), so this is the same
+// value as the reference's division at a tenth of the instructions.
 __device__ __forceinline__ rt_v3 texel_rgb(uint32_t t) {
-  return rt_v3_make((float)(int)(t & 0xFFu) / 255.999f, (float)(int)((t >> 8) & 0xFFu) / 255.999f,
-                    (float)(int)((t >> 16) & 0xFFu) / 255.999f);
+  const float k = 1.0f / 255.999f;
+  return rt_v3_make((float)(int)(t & 0xFFu) * k, (float)(int)((t >> 8) & 0xFFu) * k,
+                    (float)(int)((t >> 16) & 0xFFu) * k);
 }
 
 __device__ __forceinline__ rt_v3 tex_bilinear(const RT_KParams &P, int tex, float tx, float ty) {
@@ -798,14 +811,28 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
 #define PH_HIT  4     // traversal finished with a hit: wants shading
 #define PH_MISS 5     // traversal finished without a hit: wants the environment
 
-__global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel_sched(RT_KParams P) {
-  __shared__ uint32_t s_perm[RT_BLOCK_WAVES][RT_MAX_DEPTH * 64];
-  __shared__ unsigned long long s_acc[RT_BLOCK_WAVES][RT_TILE_PIX * 3];
-
+template <int WAVES, bool LDSN>
+__global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P) {
+  // dynamic LDS: [ top of the BVH, n_lds_nodes x 13 float4 (LDSN only) ][ per wave: perm stack, depth x 64 u32 |
+  //               accumulator tile, 64 pixels x 3 x u64 ]
+  extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  uint32_t *perm = s_perm[wave];
-  unsigned long long *acc = s_acc[wave];
+  const int n_lds = LDSN ? P.n_lds_nodes : 0;
+  const float4 *lds_nodes = smem;
+  const int perm_f4 = (P.depth > 0 ? P.depth : 1) * 16;
+  float4 *wave_base = smem + n_lds * RT_LDS_NODE_F4 + wave * (perm_f4 + 96);
+  uint32_t *perm = reinterpret_cast<uint32_t *>(wave_base);
+  unsigned long long *acc = reinterpret_cast<unsigned long long *>(wave_base + perm_f4);
+
+  if (LDSN) {                 // the workgroup copies the first n_lds nodes (level order = top of the tree) once
+    const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
+    for (int i = threadIdx.x; i < n_lds * 12; i += WAVES * 64) {
+      int nd = i / 12, q = i - nd * 12;
+      smem[nd * RT_LDS_NODE_F4 + q] = g[i];
+    }
+    __syncthreads();          // the only workgroup barrier of the kernel; waves are independent afterwards
+  }
 
   LaneCounters cn;
   cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
@@ -938,10 +965,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel_sched(RT_KPar
           cn.nodes += 1;
           int n0 = __builtin_amdgcn_readfirstlane(node);
           if (all_fast) {
-            if (__ballot(node != n0) == 0) cur = node_enter<true, true>(P, ray, n0, hit.t);   // all lanes on one node
-            else cur = node_enter<true, false>(P, ray, node, hit.t);
+            if (__ballot(node != n0) == 0) cur = node_enter<true, NODE_SCALAR>(P, ray, n0, hit.t, lds_nodes);   // all lanes on one node
+            else if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes);
+            else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
           } else {
-            cur = node_enter<false, false>(P, ray, node, hit.t);
+            cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
           }
           dirty &= ~(1u << level);
           phase = PH_POP;
@@ -962,7 +990,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel_sched(RT_KPar
             cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
             bool go = true;
             if ((dirty >> level) & 1u) {
-              float dj = slab_entry_child<false>(P, ray, node, j);
+              float dj;
+              if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4) + j, ray);
+              else dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
               if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
             }
             if (go) {
@@ -1107,9 +1137,24 @@ __global__ void rt_test_texture_kernel(RT_KParams P, int tex, int n, const float
 // ---------------------------------------------------------------------------------
 // launchers (called from rt_api.cpp)
 
-extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_blocks, int variant, hipStream_t stream) {
-  if (variant == 1) hipLaunchKernelGGL(rt_path_kernel, dim3(n_blocks), dim3(RT_BLOCK_THREADS), 0, stream, *P);
-  else hipLaunchKernelGGL(rt_path_kernel_sched, dim3(n_blocks), dim3(RT_BLOCK_THREADS), 0, stream, *P);
+// variant 1: plain while-while kernel; 2: phase-scheduled, 256-thread workgroups, nodes from L1/L2;
+// 3: phase-scheduled, one 1024-thread workgroup per CU with the top of the BVH in LDS.
+// n_waves = total wavefronts wanted; smem_bytes = dynamic LDS per workgroup (variants 2, 3).
+extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
+  if (variant == 1) {
+    hipLaunchKernelGGL(rt_path_kernel, dim3((n_waves + 3) / 4), dim3(RT_BLOCK_THREADS), 0, stream, *P);
+  } else if (variant == 2) {
+    hipLaunchKernelGGL((rt_path_kernel_sched<4, false>), dim3((n_waves + 3) / 4), dim3(256), smem_bytes, stream, *P);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<16, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((rt_path_kernel_sched<16, true>), dim3((n_waves + 15) / 16), dim3(1024), smem_bytes, stream, *P);
+  }
   return (int)hipGetLastError();
 }
 

@@ -257,6 +257,12 @@ def test_sample_texture_bilinear(oracle):
             assert np.array_equal(out, np_bilinear(keep, tu, tv)), (shape, tu, tv)
 
 
+def test_texel_scale_multiplication_is_exact_on_u8():
+    """The device computes u8 * RN(1/255.999f); the reference divides (driver.c:70-87).  Equal for all 256 inputs."""
+    i = np.arange(256).astype(F)
+    assert np.array_equal(i / F(255.999), i * (F(1.0) / F(255.999)))
+
+
 def test_sample_background_orientation(oracle):
     """u = 0.5 + atan2(z, x)/2pi, v = 0.5 - asin(y)/pi (driver.c:95-104): +y looks at row 0."""
     from raytracing_c_amd.scene import make_image

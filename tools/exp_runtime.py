@@ -36,11 +36,11 @@ def main():
     run(64, 4)
     knobs = os.environ.get("RT_EXP", "slab,bpc").split(",")
     if "kernel" in knobs:
-        for kv in (1, 2):
+        for kv in (1, 2, 3):
             os.environ["RT_KERNEL"] = str(kv)
-            for th in ((32,) if kv == 1 else (8, 16, 24, 32, 40, 48, 56, 64)):
+            for th in ((32,) if kv == 1 else (32, 40, 48, 56)):
                 os.environ["RT_SCHED_THRESH"] = str(th)
-                for slab in (16, 64):
+                for slab in (8, 16, 32):
                     print(f"kernel {kv} thresh {th:2d} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_KERNEL")
         os.environ.pop("RT_SCHED_THRESH")
