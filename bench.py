@@ -241,7 +241,7 @@ def main():
                          "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "separate passes; 2 x FETCH_SIZE + WRITE_SIZE, x 1024)" if traffic else None,
-                         "kernel": "rt_path_kernel", "launches_averaged": int(n_launches.value),
+                         "kernel": "rt_path_kernel_sched<16, true> (RT_KERNEL=3 default)", "launches_averaged": int(n_launches.value),
                          "algorithmic_bytes_per_launch": rays_per_launch * b_ray,
                          "bytes_per_ray": b_ray,
                          "note": "achieved = algorithmic scene bytes (192 N + 288 L + 112 H + 48 X + 12 M per ray, "

@@ -25,7 +25,7 @@ def main(tag):
             name = r["Name"].split("(")[0][:60]
             lines.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | "
                          f"{float(r['Percentage']):.3f} | {float(r['MinNs'])/1e6:.4f} | {float(r['MaxNs'])/1e6:.4f} |")
-            if name.startswith("rt_path_kernel"):
+            if "rt_path_kernel" in name:
                 kernel_avg_ms = float(r["AverageNs"]) / 1e6
         lines.append("")
     bench_json = os.path.join(src, f"prof_{tag}_stats.json")
