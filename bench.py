@@ -121,6 +121,12 @@ def main():
     from raytracing_c_amd.configs import load_config
     from raytracing_c_amd.multi_gpu import FramePartition, gather_tiles
 
+    # Rehearsal knobs (one-GPU boxes): RT_BENCH_DEVICE pins every rank to one device and
+    # RT_BENCH_BACKEND=gloo moves the tile gather through host memory; the driver's runs use
+    # neither (one rank per GPU, RCCL).
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if "RT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["RT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if rt.lib.rt_init(local_rank) != 0:
         raise RuntimeError("rt_init: " + rt.last_error())
@@ -129,7 +135,10 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     hs, cfg = load_config(args.config)
     if args.width:
@@ -167,7 +176,11 @@ def main():
             if rt.lib.rt_resolve(C.byref(params), accum.data_ptr(), tiles.data_ptr(), None, None, stream) != 0:
                 raise RuntimeError(rt.last_error())
             # framebuffer tiles of every rank -> every rank (RCCL all-gather over xGMI, 6 MB in total)
-            gather_tiles(tiles, all_tiles)
+            if backend == "nccl":
+                gather_tiles(tiles, all_tiles)
+            else:
+                host_all = gather_tiles(tiles.cpu(), torch.zeros(all_tiles.shape, dtype=torch.uint8))
+                all_tiles.copy_(host_all)
             if rank == 0:
                 if rt.lib.rt_untile(w, h, world, all_tiles.data_ptr(), image.data_ptr(), stream) != 0:
                     raise RuntimeError(rt.last_error())
@@ -226,8 +239,8 @@ def main():
             "config": {"workload": workload,
                        "scene": "assets/helmet.glb = self-contained models/helmet.gltf; procedural 2048x1024 "
                                 "equirect background (background.png is a missing blob); seed 0x1234ABCD",
-                       "partition": f"32x32 chunks interleaved over {world} GPU(s), RCCL all-gather of u8 tiles"
-                       if world > 1 else "single GPU"},
+                       "partition": f"32x32 chunks interleaved over {world} GPU(s), {'RCCL' if backend == 'nccl' else backend} "
+                                    "all-gather of u8 tiles" if world > 1 else "single GPU"},
             "fps": 1.0 / sec_per_step,
             "msample_per_s": w * h * s / sec_per_step / 1e6,
             "rays_per_frame": rays,
