@@ -71,6 +71,11 @@ typedef struct {
   i32 rank, world;       /* this process renders chunk c iff c % world == rank  */
   i32 slab;              /* samples per work item (0 = library default)         */
   i32 flags;             /* RT_FLAG_*                                           */
+  i32 sample_first;      /* this call traces samples [sample_first,             */
+  i32 sample_count;      /*   sample_first + sample_count) of every pixel; 0 = all.
+                            `samples` stays the pixel's total: the accumulation
+                            buffer can be filled by several calls (progressive)
+                            and resolved once                                   */
 } RT_Render_Params;
 
 enum {

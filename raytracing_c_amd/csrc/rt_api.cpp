@@ -422,6 +422,8 @@ static int check_params(RT_Render_Params const *p) {
   if (p->samples <= 0) return rt_fail("samples must be positive (got %d)", p->samples);
   if (p->max_bounces < 0) return rt_fail("max_bounces must be >= 0 (got %d)", p->max_bounces);
   if (p->world <= 0 || p->rank < 0 || p->rank >= p->world) return rt_fail("rank %d / world %d is invalid", p->rank, p->world);
+  if (p->sample_first < 0 || p->sample_count < 0 || p->sample_first + p->sample_count > p->samples)
+    return rt_fail("sample range [%d, +%d) outside [0, %d)", p->sample_first, p->sample_count, p->samples);
   return 0;
 }
 
@@ -451,11 +453,14 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   K->rank = p->rank;
   K->world = p->world;
   K->n_local_chunks = rt_local_chunk_count(p->width, p->height, p->rank, p->world);
+  K->sample_first = p->sample_first;
+  K->sample_end = p->sample_count > 0 ? p->sample_first + p->sample_count : p->samples;
+  int n_samples = K->sample_end - K->sample_first;
   int slab = p->slab > 0 ? p->slab : 16;
   int shift = 0;
-  while ((1 << shift) < slab && (1 << shift) < p->samples) shift++;
+  while ((1 << shift) < slab && (1 << shift) < n_samples) shift++;
   K->slab_shift = shift;
-  K->n_slabs = (p->samples + (1 << shift) - 1) >> shift;
+  K->n_slabs = (n_samples + (1 << shift) - 1) >> shift;
   int64_t n_work = (int64_t)K->n_local_chunks * 16 * K->n_slabs;
   if (n_work > 0x7fffffff) return rt_fail("too many work items (%lld)", (long long)n_work);
   K->n_work = (int32_t)n_work;

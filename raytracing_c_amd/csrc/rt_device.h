@@ -72,11 +72,12 @@ typedef struct {
   float focal_length;
   /* frame */
   int32_t width, height, samples, max_bounces;
+  int32_t sample_first, sample_end;   /* this launch traces samples [first, end) of every pixel */
   uint32_t seed;
   int32_t chunks_x, n_chunks;
   int32_t rank, world, n_local_chunks;
   int32_t slab_shift;          /* samples per work item = 1 << slab_shift */
-  int32_t n_slabs;             /* ceil(samples / slab)                    */
+  int32_t n_slabs;             /* ceil((sample_end - sample_first) / slab) */
   int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
   int32_t sched_thresh;        /* lanes waiting for shade/regenerate that trigger it */
   int32_t sample_major;        /* work-item index -> (pixel, sample) mapping         */

@@ -707,9 +707,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
           next_k += (int)__popcll(need);
           if (!alive && my_k < item_paths) {
             int p = P.sample_major ? (my_k & 63) : (my_k >> P.slab_shift);
-            int s = s_base + (P.sample_major ? (my_k >> 6) : (my_k & (slab - 1)));
+            int s = P.sample_first + s_base + (P.sample_major ? (my_k >> 6) : (my_k & (slab - 1)));
             int x = tile_x0 + (p & 7), y = tile_y0 + (p >> 3);
-            if (s < P.samples && x < P.width && y < P.height && P.max_bounces > 0) {
+            if (s < P.sample_end && x < P.width && y < P.height && P.max_bounces > 0) {
               alive = true;
               pix = p;
               bounce = 0;
@@ -914,9 +914,9 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
               // k -> (pixel of the tile, sample of the slab): pixel-major keeps the lanes of a wave on one or
               // two pixels, sample-major spreads them over the 64 pixels of the tile
               int p = P.sample_major ? (my_k & 63) : (my_k >> P.slab_shift);
-              int s = s_base + (P.sample_major ? (my_k >> 6) : (my_k & (slab - 1)));
+              int s = P.sample_first + s_base + (P.sample_major ? (my_k >> 6) : (my_k & (slab - 1)));
               int x = tile_x0 + (p & 7), y = tile_y0 + (p >> 3);
-              if (s < P.samples && x < P.width && y < P.height && P.max_bounces > 0) {
+              if (s < P.sample_end && x < P.width && y < P.height && P.max_bounces > 0) {
                 pix = p;
                 bounce = 0;
                 rng = rt_path_seed(P.seed, (uint32_t)(x + y * P.width), (uint32_t)s);

@@ -123,7 +123,7 @@ class RT_Counters(C.Structure):  # rt_hip.h
 class RT_Render_Params(C.Structure):  # rt_hip.h
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("max_bounces", C.c_int32),
                 ("seed", C.c_uint32), ("rank", C.c_int32), ("world", C.c_int32), ("slab", C.c_int32),
-                ("flags", C.c_int32)]
+                ("flags", C.c_int32), ("sample_first", C.c_int32), ("sample_count", C.c_int32)]
 
 
 assert C.sizeof(BVH_Node) == 192
