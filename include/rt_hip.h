@@ -109,6 +109,9 @@ extern int rt_resolve(RT_Render_Params const *params, void const *d_accum,
 extern int rt_untile(i32 width, i32 height, i32 world, void const *d_all_tiles,
                      void *d_image, void *stream);
 
+/* denoise_image() (rt_raytracer.h) on DEVICE buffers: u8[height*width*3] row-major -> same layout. */
+extern int rt_denoise(i32 width, i32 height, void const *d_src, void *d_dst, void *stream);
+
 /* Whole frame from host memory to host memory on one GPU: upload/cached scene,
  * accumulate, resolve, copy back.  pixels: u8[height*stride*components] as the
  * reference lays out Image; linear (optional): f32[height*width*3];

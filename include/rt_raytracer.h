@@ -69,6 +69,11 @@ extern void rendering_context_finish(Rendering_Context *context);
  *  and until then it only records an error. */
 extern void lightmap_bake(Image const *lightmap, Scene const *scene, isize samples);
 
+/* reference denoiser.h / denoiser.c:131-153: 3x3 luminance-sorted median,
+ * blended by neighbourhood noisiness, on u8 images in HOST memory (what driver.c:827-837 calls after
+ * the render).  Runs as one HIP kernel; n_threads is accepted and ignored.  Errors: rt_last_error(). */
+extern void denoise_image(Image const *src, Image const *dst, isize n_threads);
+
 /* Blocking convenience wrapper named by BASELINE.json's north_star; not part of
  * the reference.  Returns 0 on success, -1 on error. */
 extern int render(Scene *scene, Image *image, isize samples, isize max_bounces);

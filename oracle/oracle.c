@@ -802,3 +802,66 @@ void oracle_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out) {
 }
 
 u8 oracle_encode_u8(f32 linear) { return rt_encode_u8(linear); }
+
+/* ------------------------------------------------------------------------- */
+/* denoiser.c:13-153  (SURVEY.md section 8f #3).  Single threaded: every output pixel depends only on
+ * the source image, so the reference's chunked threading (denoiser.c:51-129) does not affect results. */
+
+#define DENOISING_THRESHOLD  0.0125f       /* denoiser.c:13 */
+#define NEIGHBOURHOOD_WEIGHT 5             /* denoiser.c:14 */
+
+/* denoiser.c:20-30: clamp-to-edge fetch, u8 / 255.999f */
+static void dn_sample(Image const *image, isize x, isize y, f32 rgb[3]) {
+  if (x < 0) x = 0;
+  if (y < 0) y = 0;
+  if (x >= image->width)  x = image->width - 1;
+  if (y >= image->height) y = image->height - 1;
+  rgb[0] = rgb[1] = rgb[2] = 0.0f;
+  isize nc = image->components < 3 ? image->components : 3;
+  for (isize c = 0; c < nc; c++) {
+    rgb[c] = image->pixels.data[(x + y * image->stride) * image->components + c] / 255.999f;
+  }
+}
+
+void oracle_denoise_image(Image const *src, Image const *dst) {
+  isize width = src->width, height = src->height;
+  for (isize y = 0; y < height; y++) {
+    for (isize x = 0; x < width; x++) {
+      f32 colors[9][4];
+      f32 original[4] = {0, 0, 0, 0};
+      isize n_colors = 0;
+      for (isize yo = -1; yo < 2; yo++) {
+        for (isize xo = -1; xo < 2; xo++) {
+          f32 color[4];
+          dn_sample(src, x + xo, y + yo, color);
+          color[3] = color[0] * 0.2126f + color[1] * 0.7152f + color[2] * 0.0722f;     /* denoiser.c:16-18 */
+          if (xo == 0 && yo == 0) memcpy(original, color, sizeof color);
+          /* denoiser.c:85-101: insertion before the first strictly brighter entry */
+          bool found = false;
+          for (isize i = 0; i < n_colors; i++) {
+            if (colors[i][3] > color[3]) {
+              found = true;
+              for (isize j = n_colors; j > i; j--) memcpy(colors[j], colors[j - 1], sizeof color);
+              memcpy(colors[i], color, sizeof color);
+              break;
+            }
+          }
+          if (!found) memcpy(colors[n_colors], color, sizeof color);
+          n_colors += 1;
+        }
+      }
+      f32 const *median = colors[4];                    /* denoiser.c:104 */
+      f32 mean = 0;
+      for (isize i = 1; i < 8; i++) mean += colors[i][3];     /* all but the darkest and the brightest */
+      mean /= 7;
+      f32 noisiness = rt_absf(median[3] - mean);
+      f32 diff = rt_absf(median[3] - original[3]) - noisiness * NEIGHBOURHOOD_WEIGHT;
+      diff = rt_clampf(diff, 0.0f, DENOISING_THRESHOLD) / DENOISING_THRESHOLD;
+      isize nc = dst->components < 3 ? dst->components : 3;
+      for (isize c = 0; c < nc; c++) {                    /* store_pixel, denoiser.c:32-41 */
+        f32 v = rt_lerpf(original[c], median[c], diff);
+        dst->pixels.data[(x + y * dst->stride) * dst->components + c] = (u8)(v * 255.999f);
+      }
+    }
+  }
+}

@@ -90,6 +90,10 @@ void oracle_disney_shade(PBR_Shader_Data const *data, Shader_Input const *in, u3
 void oracle_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
 u8   oracle_encode_u8(f32 linear);
 
+/* denoiser.c:51-153: 3x3 luminance-sorted median blended by neighbourhood noisiness; src and dst are
+ * u8 images of equal size (components >= 3 are filtered, like min(components, 3) in denoiser.c:24,36) */
+void oracle_denoise_image(Image const *src, Image const *dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,8 @@ int rt_launch_test_math(int op, int n, const float *x, const float *y, float *ou
 int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
                          hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
+int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
+                      const uint8_t *src, uint8_t *dst, hipStream_t stream);
 }
 
 // ---------------------------------------------------------------------------------
@@ -730,6 +732,46 @@ extern "C" void lightmap_bake(Image const *, Scene const *, isize) {
 
 extern "C" int render(Scene *scene, Image *image, isize samples, isize max_bounces) {
   return rt_render_frame(scene, image, samples, max_bounces, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------
+// denoiser (reference denoiser.h / denoiser.c:131-153), SURVEY.md section 8f #3
+
+extern "C" int rt_denoise(i32 width, i32 height, void const *d_src, void *d_dst, void *stream) {
+  if (ensure_device() != 0) return -1;
+  if (width <= 0 || height <= 0 || !d_src || !d_dst || d_src == d_dst) return rt_fail("rt_denoise: bad arguments");
+  int rc = rt_launch_denoise(width, height, width, 3, width, 3, (const uint8_t *)d_src, (uint8_t *)d_dst, (hipStream_t)stream);
+  if (rc != 0) return rt_fail("denoise kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+static int denoise_host(Image const *src, Image const *dst) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (!src || !dst || !src->pixels.data || !dst->pixels.data) return rt_fail("denoise_image: NULL image");
+  if (src->pixels.data == dst->pixels.data) return rt_fail("denoise_image: src and dst must differ (denoiser.c:134)");
+  if (src->width != dst->width || src->height != dst->height) return rt_fail("denoise_image: size mismatch");
+  if (src->components < 1 || dst->components < 1 || src->stride < src->width || dst->stride < dst->width)
+    return rt_fail("denoise_image: bad layout");
+  size_t sb = (size_t)src->stride * src->height * src->components;
+  size_t db = (size_t)dst->stride * dst->height * dst->components;
+  uint8_t *ds = nullptr, *dd = nullptr;
+  HIP_TRY(hipMalloc(&ds, sb));
+  HIP_TRY(hipMalloc(&dd, db));
+  HIP_TRY(hipMemcpy(ds, src->pixels.data, sb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dd, dst->pixels.data, db, hipMemcpyHostToDevice));     // components beyond 3 keep their values
+  int rc = rt_launch_denoise((int)src->width, (int)src->height, (int)src->stride, (int)src->components,
+                             (int)dst->stride, (int)dst->components, ds, dd, nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(dst->pixels.data, dd, db, hipMemcpyDeviceToHost);
+  (void)hipFree(ds);
+  (void)hipFree(dd);
+  if (rc != 0) return rt_fail("denoise_image failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+extern "C" void denoise_image(Image const *src, Image const *dst, isize n_threads) {
+  (void)n_threads;      // the reference's CPU thread count (denoiser.c:131); one kernel launch here
+  denoise_host(src, dst);
 }
 
 // ---------------------------------------------------------------------------------

@@ -114,6 +114,9 @@ def _declare(d):
     d.render.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize]
     d.lightmap_bake.argtypes = [P(abi.Image), P(abi.Scene), abi.isize]
     d.lightmap_bake.restype = None
+    d.denoise_image.argtypes = [P(abi.Image), P(abi.Image), abi.isize]
+    d.denoise_image.restype = None
+    d.rt_denoise.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
 
 
 lib = _Lazy()
