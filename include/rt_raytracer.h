@@ -63,10 +63,11 @@ extern bool rendering_context_is_finished(Rendering_Context *context);
 /* reference raytracer.c:790-794 */
 extern void rendering_context_finish(Rendering_Context *context);
 
-/* reference raytracer.c:722-784: UV-space light baking, a second caller of the
- * path loop that the reference driver never invokes.  Exported so the symbol
- * set is complete; the GPU implementation is scheduled after the render path
- *  and until then it only records an error. */
+/* reference raytracer.c:722-784: UV-space light baking, the second caller of the
+ * path loop (the reference driver never invokes it).  Rasterises every triangle in
+ * UV space on the GPU and bakes `samples` cosine-weighted 8-bounce paths per texel
+ * into the u8 lightmap (host memory).  Texels covered by several triangles keep the
+ * last triangle's value, texels outside the image are skipped; errors: rt_last_error(). */
 extern void lightmap_bake(Image const *lightmap, Scene const *scene, isize samples);
 
 /* reference denoiser.h / denoiser.c:131-153: 3x3 luminance-sorted median,

@@ -865,3 +865,81 @@ void oracle_denoise_image(Image const *src, Image const *dst) {
     }
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* raytracer.c:722-784  lightmap_bake               */
+
+/* common.h:26-42 */
+static f32 rand_f32_range(f32 lo, f32 hi) { return rand_f32() * (hi - lo) + lo; }
+
+static rt_v3 rand_vec3(void) {
+  for (;;) {
+    rt_v3 p;
+    p.x = rand_f32_range(-1.0f, 1.0f);
+    p.y = rand_f32_range(-1.0f, 1.0f);
+    p.z = rand_f32_range(-1.0f, 1.0f);
+    f32 lensq = rt_v3_dot(p, p);
+    if (RT_EPS < lensq && lensq <= 1.0f) return rt_v3_scale(p, 1.0f / rt_sqrtf(lensq));
+  }
+}
+
+static f32 min3(f32 a, f32 b, f32 c) { f32 m = b < c ? b : c; return a < m ? a : m; }    /* min(a, min(b, c)) */
+static f32 max3(f32 a, f32 b, f32 c) { f32 m = b > c ? b : c; return a > m ? a : m; }
+
+void oracle_lightmap_bake(Image const *lightmap, Scene const *scene, isize samples, Oracle_Config const *cfg) {
+  memset(&tl_counters, 0, sizeof tl_counters);
+  f32 lw = (f32)lightmap->width, lh = (f32)lightmap->height;
+  Triangles const *T = &scene->triangles;
+  for (isize i = 0; i < T->len; i++) {
+    Triangle_AOS aos = T->aos[i];
+    i32 min_x = (i32)(min3(aos.tex_coords_a.x, aos.tex_coords_b.x, aos.tex_coords_c.x) * lw);
+    i32 max_x = (i32)(max3(aos.tex_coords_a.x, aos.tex_coords_b.x, aos.tex_coords_c.x) * lw);
+    i32 min_y = (i32)(min3(aos.tex_coords_a.y, aos.tex_coords_b.y, aos.tex_coords_c.y) * lh);
+    i32 max_y = (i32)(max3(aos.tex_coords_a.y, aos.tex_coords_b.y, aos.tex_coords_c.y) * lh);
+
+    f32 p0x = aos.tex_coords_a.x * lw, p0y = aos.tex_coords_a.y * lh;
+    f32 p1x = aos.tex_coords_b.x * lw, p1y = aos.tex_coords_b.y * lh;
+    f32 p2x = aos.tex_coords_c.x * lw, p2y = aos.tex_coords_c.y * lh;
+    f32 denom = (p1y - p2y) * (p0x - p2x) + (p2x - p1x) * (p0y - p2y);
+
+    for (i32 y = min_y; y < max_y + 1; y++) {
+      for (i32 x = min_x; x < max_x + 1; x++) {
+        if (x < 0 || y < 0 || x >= lightmap->width || y >= lightmap->height) continue;   /* reference: out of bounds */
+        f32 px = (f32)x, py = (f32)y;
+        f32 w0 = ((p1y - p2y) * (px - p2x) + (p2x - p1x) * (py - p2y)) / denom;
+        f32 w1 = ((p2y - p0y) * (px - p2x) + (p0x - p2x) * (py - p2y)) / denom;
+        f32 w2 = 1.0f - w0 - w1;
+        if (w0 >= -RT_EPS && w1 >= -RT_EPS && w2 >= -RT_EPS) {
+          rt_v3 position = rt_v3_make(T->x[0][i] * w0 + T->x[1][i] * w1 + T->x[2][i] * w2,
+                                      T->y[0][i] * w0 + T->y[1][i] * w1 + T->y[2][i] * w2,
+                                      T->z[0][i] * w0 + T->z[1][i] * w1 + T->z[2][i] * w2);
+          rt_v3 normal = rt_v3_make(aos.normal_a.x * w0 + aos.normal_b.x * w1 + aos.normal_c.x * w2,
+                                    aos.normal_a.y * w0 + aos.normal_b.y * w1 + aos.normal_c.y * w2,
+                                    aos.normal_a.z * w0 + aos.normal_b.z * w1 + aos.normal_c.z * w2);
+          rt_v3 accumulated = rt_v3_make(0, 0, 0);
+          Ray r;
+          r.position = U(rt_v3_add(position, rt_v3_scale(normal, RT_EPS)));
+          r.direction = U(rt_v3_make(0, 0, 0));
+          random_state = rt_path_seed(cfg->seed, (u32)(x + y * (i32)lightmap->width), (u32)i);
+          for (isize s = 0; s < samples; s++) {
+            f32 cosv;
+            i32 guard = 0;
+            for (;;) {
+              rt_v3 d = rand_vec3();
+              cosv = rt_v3_dot(d, normal);
+              if (cosv > 0.0f) { r.direction = U(d); break; }
+              if (++guard >= 64) { cosv = 0.0f; r.direction = U(d); break; }   /* zero/NaN normal: the reference would spin forever */
+            }
+            accumulated = rt_v3_add(accumulated, rt_v3_scale(cast_ray(scene, cfg, r, 8), cosv));
+          }
+          f32 v[3] = { accumulated.x / (f32)samples, accumulated.y / (f32)samples, accumulated.z / (f32)samples };
+          for (int c = 0; c < 3; c++) {
+            f32 q = v[c] > 0.0f ? v[c] : 0.0f;          /* NaN and negatives -> 0 */
+            q = q > 255.0f ? 255.0f : q;
+            lightmap->pixels.data[(x + y * lightmap->stride) * lightmap->components + c] = (u8)q;
+          }
+        }
+      }
+    }
+  }
+}

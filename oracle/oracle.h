@@ -90,6 +90,13 @@ void oracle_disney_shade(PBR_Shader_Data const *data, Shader_Input const *in, u3
 void oracle_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
 u8   oracle_encode_u8(f32 linear);
 
+/* raytracer.c:722-784: UV-space light baking.  Texels covered by several triangles
+ * keep the LAST triangle's value (the reference's loop order); texels outside the image are skipped (the
+ * reference would write out of bounds); per-texel RNG seeding rt_path_seed(seed, x + y*width, triangle)
+ * replaces the reference's running thread-local stream; the f32 -> u8 store is the reference's plain
+ * conversion (no *255), clamped to [0, 255]. */
+void oracle_lightmap_bake(Image const *lightmap, Scene const *scene, isize samples, Oracle_Config const *config);
+
 /* denoiser.c:51-153: 3x3 luminance-sorted median blended by neighbourhood noisiness; src and dst are
  * u8 images of equal size (components >= 3 are filtered, like min(components, 3) in denoiser.c:24,36) */
 void oracle_denoise_image(Image const *src, Image const *dst);

@@ -30,6 +30,8 @@ int rt_launch_test_math(int op, int n, const float *x, const float *y, float *ou
 int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
                          hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
+int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int lw, int lh, int stride, int comp,
+                       int samples, int *owner, uint8_t *pixels, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
 }
@@ -387,6 +389,8 @@ extern "C" void rt_scene_invalidate(Scene const *scene) {
 
 extern "C" i64 rt_scene_device_bytes(RT_Device_Scene const *dscene) { return dscene ? dscene->bytes : 0; }
 
+static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d);
+
 static RT_Device_Scene *cached_scene_locked(Scene const *scene) {
   auto it = g_scene_cache.find(scene);
   if (it != g_scene_cache.end()) {
@@ -726,8 +730,52 @@ extern "C" void rendering_context_finish(Rendering_Context *context) {
   while (__atomic_load_n(&context->n_threads, __ATOMIC_SEQ_CST) > 0) std::this_thread::yield();
 }
 
-extern "C" void lightmap_bake(Image const *, Scene const *, isize) {
-  rt_fail("lightmap_bake is not implemented on the GPU yet (unused by the reference driver; SURVEY.md 8f #4)");
+// raytracer.c:722-784 on the GPU; semantics and the three documented choices
+// (last triangle wins, texels outside the image skipped, per-texel seeding) are in oracle/oracle.h.
+static int lightmap_bake_locked(Image const *lightmap, Scene const *scene, isize samples) {
+  if (ensure_device() != 0) return -1;
+  if (!lightmap || !scene || !lightmap->pixels.data) return rt_fail("lightmap_bake: NULL argument");
+  if (lightmap->pixel_type != PT_u8 || lightmap->components < 3) return rt_fail("lightmap_bake: need a u8 image with >= 3 components");
+  if (samples <= 0 || lightmap->width <= 0 || lightmap->height <= 0 || lightmap->stride < lightmap->width)
+    return rt_fail("lightmap_bake: bad size or sample count");
+  RT_Device_Scene *d = cached_scene_locked(scene);
+  if (!d) return -1;
+  RT_KParams K;
+  scene_only_kparams(&K, d);
+  K.max_bounces = 8;            // cast_ray(scene, r, 8), raytracer.c:774
+  K.seed = g_seed;
+  const Triangles &T = scene->triangles;
+  std::vector<float> verts((size_t)T.len * 9);
+  for (int i = 0; i < T.len; i++)
+    for (int k = 0; k < 3; k++) {
+      verts[(size_t)i * 9 + 0 + k] = T.x[k][i];
+      verts[(size_t)i * 9 + 3 + k] = T.y[k][i];
+      verts[(size_t)i * 9 + 6 + k] = T.z[k][i];
+    }
+  size_t pb = (size_t)lightmap->stride * lightmap->height * lightmap->components;
+  size_t ob = (size_t)lightmap->width * lightmap->height * sizeof(int);
+  float *dv = nullptr;
+  int *dow = nullptr;
+  uint8_t *dp = nullptr;
+  HIP_TRY(hipMalloc(&dv, verts.size() * sizeof(float)));
+  HIP_TRY(hipMalloc(&dow, ob));
+  HIP_TRY(hipMalloc(&dp, pb));
+  HIP_TRY(hipMemcpy(dv, verts.data(), verts.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dow, 0xFF, ob));                                        // owner = -1
+  HIP_TRY(hipMemcpy(dp, lightmap->pixels.data, pb, hipMemcpyHostToDevice));   // untouched texels keep their value
+  int rc = rt_launch_lightmap(&K, dv, T.len, (int)lightmap->width, (int)lightmap->height, (int)lightmap->stride,
+                              (int)lightmap->components, (int)samples, dow, dp, nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(lightmap->pixels.data, dp, pb, hipMemcpyDeviceToHost);
+  (void)hipFree(dv);
+  (void)hipFree(dow);
+  (void)hipFree(dp);
+  if (rc != 0) return rt_fail("lightmap_bake failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+extern "C" void lightmap_bake(Image const *lightmap, Scene const *scene, isize samples) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  lightmap_bake_locked(lightmap, scene, samples);
 }
 
 extern "C" int render(Scene *scene, Image *image, isize samples, isize max_bounces) {

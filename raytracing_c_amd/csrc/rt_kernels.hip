@@ -1081,6 +1081,137 @@ __global__ void rt_untile_kernel(int width, int height, int chunks_x, int n_chun
 }
 
 // ---------------------------------------------------------------------------------
+// lightmap_bake (raytracer.c:722-784): the second caller of the path loop.
+// Pass 1 rasterises every triangle in UV space and records, per texel, the LAST triangle that covers it
+// (the reference's sequential loop overwrites in triangle order); pass 2 bakes each owned texel:
+// `samples` cosine-weighted paths of 8 bounces from the interpolated surface point.
+
+// barycentric weights of texel (x, y) for the UV triangle (p0, p1, p2), raytracer.c:733-747
+__device__ __forceinline__ bool lightmap_weights(float p0x, float p0y, float p1x, float p1y, float p2x, float p2y,
+                                                 int x, int y, float &w0, float &w1, float &w2) {
+  float denom = (p1y - p2y) * (p0x - p2x) + (p2x - p1x) * (p0y - p2y);
+  float px = (float)x, py = (float)y;
+  w0 = ((p1y - p2y) * (px - p2x) + (p2x - p1x) * (py - p2y)) / denom;
+  w1 = ((p2y - p0y) * (px - p2x) + (p0x - p2x) * (py - p2y)) / denom;
+  w2 = 1.0f - w0 - w1;
+  return w0 >= -RT_EPS && w1 >= -RT_EPS && w2 >= -RT_EPS;
+}
+
+__device__ __forceinline__ float min3f(float a, float b, float c) { float m = b < c ? b : c; return a < m ? a : m; }
+__device__ __forceinline__ float max3f(float a, float b, float c) { float m = b > c ? b : c; return a > m ? a : m; }
+
+__global__ void rt_lightmap_owner_kernel(RT_KParams P, int n_tris, int lw, int lh, int *owner) {
+  int i = blockIdx.x;
+  if (i >= n_tris) return;
+  const float *tb = P.tris + (size_t)i * 28;
+  float uax = tb[7], uay = tb[11], ubx = tb[15], uby = tb[19], ucx = tb[23], ucy = tb[24];
+  float flw = (float)lw, flh = (float)lh;
+  int min_x = (int)(min3f(uax, ubx, ucx) * flw), max_x = (int)(max3f(uax, ubx, ucx) * flw);
+  int min_y = (int)(min3f(uay, uby, ucy) * flh), max_y = (int)(max3f(uay, uby, ucy) * flh);
+  float p0x = uax * flw, p0y = uay * flh, p1x = ubx * flw, p1y = uby * flh, p2x = ucx * flw, p2y = ucy * flh;
+  // clip the loop to the image (texels outside are skipped, see oracle.h)
+  int x0 = min_x < 0 ? 0 : min_x, x1 = max_x >= lw ? lw - 1 : max_x;
+  int y0 = min_y < 0 ? 0 : min_y, y1 = max_y >= lh ? lh - 1 : max_y;
+  int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+  if (bw <= 0 || bh <= 0) return;
+  for (int t = threadIdx.x; t < bw * bh; t += blockDim.x) {
+    int x = x0 + t % bw, y = y0 + t / bw;
+    float w0, w1, w2;
+    if (lightmap_weights(p0x, p0y, p1x, p1y, p2x, p2y, x, y, w0, w1, w2)) atomicMax(&owner[y * lw + x], i);
+  }
+}
+
+// raytracer.c:505-558 for one ray, sequential per lane (used by the lightmap; the frame kernels schedule
+// the same steps per phase instead)
+__device__ __forceinline__ rt_v3 cast_ray_lane(const RT_KParams &P, rt_v3 org, rt_v3 dir, uint32_t &rng,
+                                               uint32_t *perm, int lane, LaneCounters &cn) {
+  rt_v3 tint = rt_v3_make(1, 1, 1), emis = rt_v3_make(0, 0, 0), radiance = rt_v3_make(0, 0, 0);
+  int bounce = 0;
+  bool done = P.max_bounces <= 0;
+  while (!done) {
+    Ray3 ray;
+    ray_setup(ray, org, dir);
+    HitRec hit;
+    if (ray.fast) trace_ray<true>(P, ray, hit, perm, lane, cn);
+    else trace_ray<false>(P, ray, hit, perm, lane, cn);
+    if (hit.tri >= 0) {
+      done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
+    } else {
+      cn.bgs += 1;
+      radiance = rt_v3_add(rt_v3_mul(background_lookup(P, dir), tint), emis);
+      done = true;
+    }
+  }
+  return radiance;
+}
+
+// common.h:30-42
+__device__ __forceinline__ rt_v3 rand_vec3_dev(uint32_t &rng) {
+  for (;;) {
+    rt_v3 p;
+    p.x = rt_rand_f32(&rng) * (1.0f - -1.0f) + -1.0f;
+    p.y = rt_rand_f32(&rng) * (1.0f - -1.0f) + -1.0f;
+    p.z = rt_rand_f32(&rng) * (1.0f - -1.0f) + -1.0f;
+    float lensq = rt_v3_dot(p, p);
+    if (RT_EPS < lensq && lensq <= 1.0f) return rt_v3_scale(p, 1.0f / rt_sqrtf(lensq));
+  }
+}
+
+__global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_lightmap_bake_kernel(RT_KParams P, const float *verts, int lw, int lh,
+                                                                            int stride, int comp, int samples,
+                                                                            const int *owner, uint8_t *pixels) {
+  __shared__ uint32_t s_perm[RT_BLOCK_WAVES][RT_MAX_DEPTH * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= lw * lh) return;
+  int i = owner[idx];
+  if (i < 0) return;
+  int x = idx % lw, y = idx / lw;
+  const float *tb = P.tris + (size_t)i * 28;
+  float flw = (float)lw, flh = (float)lh;
+  float w0, w1, w2;
+  lightmap_weights(tb[7] * flw, tb[11] * flh, tb[15] * flw, tb[19] * flh, tb[23] * flw, tb[24] * flh, x, y, w0, w1, w2);
+  const float *v = verts + (size_t)i * 9;       // x0 x1 x2 y0 y1 y2 z0 z1 z2 (original vertices, scene.h:53-60)
+  rt_v3 position = rt_v3_make(v[0] * w0 + v[1] * w1 + v[2] * w2, v[3] * w0 + v[4] * w1 + v[5] * w2,
+                              v[6] * w0 + v[7] * w1 + v[8] * w2);
+  rt_v3 normal = rt_v3_make(tb[4] * w0 + tb[8] * w1 + tb[12] * w2, tb[5] * w0 + tb[9] * w1 + tb[13] * w2,
+                            tb[6] * w0 + tb[10] * w1 + tb[14] * w2);
+  rt_v3 org = rt_v3_add(position, rt_v3_scale(normal, RT_EPS));
+  uint32_t rng = rt_path_seed(P.seed, (uint32_t)(x + y * lw), (uint32_t)i);
+  LaneCounters cn;
+  cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
+  rt_v3 acc = rt_v3_make(0, 0, 0);
+  for (int s = 0; s < samples; s++) {
+    float cosv;
+    rt_v3 d;
+    int guard = 0;
+    for (;;) {
+      d = rand_vec3_dev(rng);
+      cosv = rt_v3_dot(d, normal);
+      if (cosv > 0.0f) break;
+      if (++guard >= 64) { cosv = 0.0f; break; }
+    }
+    acc = rt_v3_add(acc, rt_v3_scale(cast_ray_lane(P, org, d, rng, s_perm[wave], lane, cn), cosv));
+  }
+  float out[3] = {acc.x / (float)samples, acc.y / (float)samples, acc.z / (float)samples};
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float q = out[c] > 0.0f ? out[c] : 0.0f;
+    q = q > 255.0f ? 255.0f : q;
+    pixels[((size_t)x + (size_t)y * stride) * comp + c] = (uint8_t)q;
+  }
+}
+
+extern "C" int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int lw, int lh, int stride, int comp,
+                                  int samples, int *owner, uint8_t *pixels, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_lightmap_owner_kernel, dim3(n_tris), dim3(64), 0, stream, *P, n_tris, lw, lh, owner);
+  int n = lw * lh;
+  hipLaunchKernelGGL(rt_lightmap_bake_kernel, dim3((n + RT_BLOCK_THREADS - 1) / RT_BLOCK_THREADS), dim3(RT_BLOCK_THREADS), 0,
+                     stream, *P, verts, lw, lh, stride, comp, samples, owner, pixels);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // unit-level kernels for parity tests
 
 __global__ void rt_test_math_kernel(int op, int n, const float *x, const float *y, float *out) {

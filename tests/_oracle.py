@@ -68,6 +68,8 @@ def load(path=None):
     d.oracle_disney_shade.restype = None
     d.oracle_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
     d.oracle_math.restype = None
+    d.oracle_lightmap_bake.argtypes = [P(abi.Image), P(abi.Scene), abi.isize, P(Oracle_Config)]
+    d.oracle_lightmap_bake.restype = None
     d.oracle_denoise_image.argtypes = [P(abi.Image), P(abi.Image)]
     d.oracle_denoise_image.restype = None
     d.oracle_encode_u8.argtypes = [C.c_float]
