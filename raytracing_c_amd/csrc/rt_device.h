@@ -79,7 +79,9 @@ typedef struct {
   int32_t slab_shift;          /* samples per work item = 1 << slab_shift */
   int32_t n_slabs;             /* ceil((sample_end - sample_first) / slab) */
   int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
-  int32_t sched_thresh;        /* lanes waiting for shade/regenerate that trigger it */
+  int32_t sched_thresh;        /* lanes waiting for environment/regenerate that trigger it */
+  int32_t sched_thresh_shade;  /* lanes waiting for shading that trigger it           */
+  int32_t sched_split;         /* 1: shading scheduled apart from environment+regen   */
   int32_t sample_major;        /* work-item index -> (pixel, sample) mapping         */
   int32_t n_lds_nodes;         /* BVH nodes [0, n) are also in the workgroup's LDS   */
   /* outputs */

@@ -180,7 +180,9 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
   uint32_t w = 0, n_inf = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    w |= (uint32_t)j << (3 * rank[j]);
+    int sh;       // 3 * rank as one full-rate v_lshl_add_u32 (hipcc turns r + 2r into a quarter-rate v_mul_lo_u32)
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(sh) : "v"(rank[j]));
+    w |= (uint32_t)j << sh;
     n_inf += ((uint32_t)d[j] + 0x00800000u) >> 31;          // 1 iff d[j] == +inf
   }
   return w | ((8u - n_inf) << 24);
@@ -845,6 +847,7 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
   const int item_paths = RT_TILE_PIX << P.slab_shift;
   const int leaf_level = P.depth - 1;
   const int thresh = P.sched_thresh;
+  const int thresh_shade = P.sched_thresh_shade;
 
   for (;;) {
     // ---- dequeue one work item (wave-uniform).  Items are small (8x8 pixels x 16 samples by default):
@@ -882,18 +885,34 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
       const bool can_regen = next_k < item_paths;
       const int nN = (int)__popcll(__ballot(phase == PH_NODE));
       const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
-      const int nS = (int)__popcll(__ballot(phase == PH_HIT || phase == PH_MISS || (can_regen && phase == PH_NEED)));
-      if (nN + nL + nS == 0) break;          // every lane idle and the item has no paths left
+      const int nH = (int)__popcll(__ballot(phase == PH_HIT));
+      const int nE = (int)__popcll(__ballot(phase == PH_MISS || (can_regen && phase == PH_NEED)));
+      if (nN + nL + nH + nE == 0) break;          // every lane idle and the item has no paths left
 
-      if (nS >= thresh || nN + nL == 0) {
-        // ================= S: shade, environment, regenerate =================
+      // Block choice.  Shading is by far the most expensive block (~2 200 VALU instructions against ~330 for
+      // a node), so it gets its own threshold: it runs when thresh_shade lanes wait for it; environment +
+      // regeneration (~750) when thresh lanes wait; traversal otherwise; with nothing traversing, whatever waits.
+      const bool traversing = nN + nL > 0;
+      bool run_shade, run_env;
+      if (P.sched_split) {
+        run_shade = nH > 0 && (nH >= thresh_shade || (!traversing && nE < thresh));
+        run_env = !run_shade && nE > 0 && (nE >= thresh || !traversing);
+      } else {              // one combined block: shade + environment + regenerate once `thresh` lanes wait for any of them
+        const bool both = (nH + nE >= thresh) || !traversing;
+        run_shade = both && nH > 0;
+        run_env = both && nE > 0;
+      }
+
+      if (run_shade || run_env) {
         bool  done = false, start = false;
         rt_v3 radiance = rt_v3_make(0, 0, 0);
         rt_v3 org = ray.o, dir = ray.d;
-        if (phase == PH_HIT) {
+        if (run_shade && phase == PH_HIT) {
+          // ================= SHADE: material evaluation of the closest hits =================
           done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
           start = !done;
-        } else if (phase == PH_MISS) {
+        } else if (run_env && phase == PH_MISS) {
+          // ================= ENV: environment for the misses =================
           cn.bgs += 1;
           rt_v3 bg = background_lookup(P, dir);
           radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
@@ -905,7 +924,8 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
           atomicAdd(&acc[pix * 3 + 2], (unsigned long long)rt_accum_quantize(radiance.z));
           phase = PH_NEED;
         }
-        if (can_regen) {
+        if (run_env && can_regen) {
+          // ================= REGEN: idle lanes take the next (pixel, sample) of the item =================
           unsigned long long need = __ballot(phase == PH_NEED);
           if (need) {
             int my_k = next_k + (int)__popcll(need & ((1ull << lane) - 1ull));

@@ -44,6 +44,19 @@ def main():
                     print(f"kernel {kv} thresh {th:2d} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_KERNEL")
         os.environ.pop("RT_SCHED_THRESH")
+    if "shade" in knobs:
+        os.environ["RT_SCHED_SPLIT"] = "0"
+        for th in (32, 40, 48, 56):
+            os.environ["RT_SCHED_THRESH"] = str(th)
+            print(f"combined S thresh {th:2d}: {run(16, 4):8.3f} ms", flush=True)
+        os.environ["RT_SCHED_SPLIT"] = "1"
+        for ts in (16, 24, 32):
+            os.environ["RT_SCHED_THRESH_SHADE"] = str(ts)
+            for th in (24, 32, 40, 48):
+                os.environ["RT_SCHED_THRESH"] = str(th)
+                print(f"thresh_shade {ts:2d} thresh {th:2d}: {run(16, 4):8.3f} ms", flush=True)
+        os.environ.pop("RT_SCHED_THRESH_SHADE")
+        os.environ.pop("RT_SCHED_THRESH")
     if "map" in knobs:
         for sm in (0, 1):
             os.environ["RT_SAMPLE_MAJOR"] = str(sm)
