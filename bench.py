@@ -61,6 +61,23 @@ def cpu_baseline(hs, cfg, target_seconds):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a container may see every host CPU but be limited by a cgroup quota (a 1-GPU box gets a 16-CPU share)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = max(1, min(cores, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = max(1, min(cores, int(round(q / p_))))
+            break
+        except Exception:
+            continue
+    if "RT_CPU_THREADS" in os.environ:
+        cores = int(os.environ["RT_CPU_THREADS"])
     lib = None
     # rebuild the checker for this host's ISA (-march=native) when a compiler is present
     try:
