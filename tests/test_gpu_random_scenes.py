@@ -1,0 +1,101 @@
+"""Randomised scenes: rare data-dependent branches need their own inputs.
+
+Procedural triangle soups with duplicated triangles (exactly equal hit distances -> the reference's first-found
+tie rule, raytracer.c:159,464), degenerate and axis-aligned geometry, UVs outside [0,1], and materials that
+switch on every optional term of driver.c:350-409 (sheen, anisotropy, emission, metalness beyond the 0.9 clamp,
+tiny roughness, normal / albedo / metal-roughness / emission textures).  GPU == oracle, bit for bit.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_scene(seed, n_tris, depth_hint=None):
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.loaders import camera_from_trs
+    from raytracing_c_amd.scene import Material, build_scene
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-1, 1, (n_tris, 1, 3))
+    P = (c + rng.normal(size=(n_tris, 3, 3)) * rng.choice([0.05, 0.3, 0.8], (n_tris, 1, 1))).astype(np.float32)
+    # exact duplicates (ties), a degenerate triangle, axis-aligned quads on the planes x=0 / y=0
+    k = max(2, n_tris // 10)
+    P[-k:] = P[:k]
+    P[k] = P[k][[0, 0, 0]]
+    if n_tris > 12:
+        P[k + 1] = [[0, -1, -1], [0, 1, -1], [0, 1, 1]]
+        P[k + 2] = [[-1, 0, -1], [1, 0, -1], [1, 0, 1]]
+    e1, e2 = P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]
+    fn = np.cross(e1, e2)
+    fn = fn / np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    N = (fn[:, None, :] + rng.normal(size=(n_tris, 3, 3)) * 0.2).astype(np.float32)     # perturbed vertex normals
+    UV = rng.uniform(-1.5, 2.5, (n_tris, 3, 2)).astype(np.float32)
+    images = [rng.integers(0, 256, (h, w, comp), dtype=np.uint8) for (h, w, comp) in
+              ((16, 16, 3), (8, 32, 4), (5, 7, 3), (32, 32, 3))]
+    mats = []
+    for m in range(6):
+        mt = Material(base_color=tuple(rng.uniform(0, 1, 3)), emission=tuple(rng.choice([0.0, 0.0, 2.0], 3)),
+                      roughness=float(rng.choice([0.0, 0.001, 0.2, 0.7, 1.5])), metalness=float(rng.choice([0, 0.5, 0.95, 1.0])),
+                      normal_map_strength=float(rng.choice([0.0, 0.5, 1.0])), sheen=float(rng.choice([0.0, 0.6])),
+                      sheen_tint=float(rng.uniform(0, 1)), anisotropic_strength=float(rng.choice([0.0, 0.7])))
+        if m % 2 == 0:
+            mt.texture_albedo = int(rng.integers(0, 4))
+            mt.texture_normal = int(rng.integers(0, 4))
+        if m % 3 == 0:
+            mt.texture_metal_roughness = int(rng.integers(0, 4))
+            mt.texture_emission = int(rng.integers(0, 4))
+        mats.append(mt)
+    ids = rng.integers(0, len(mats), n_tris)
+    cam = camera_from_trs((0.1, 0.2, 3.5))
+    bg = procedural_background(64, 32)
+    return build_scene(P, N, UV, ids, mats, images, cam, 0.9, bg)
+
+
+@pytest.mark.parametrize("seed,n_tris", [(1, 5), (2, 8), (3, 9), (4, 64), (5, 65), (6, 400), (7, 513), (8, 3000)])
+def test_random_scene_bit_exact(oracle, seed, n_tris):
+    import raytracing_c_amd as rt
+    from tests import _oracle
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    hs = make_scene(seed, n_tris)
+    w, h, s, b = 72, 56, 6, 7
+    want = _oracle.render(hs, w, h, s, b, seed=seed)
+    got = rt.render_frame(hs, w, h, s, b, seed=seed, want_linear=True, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    c = got["counters"]
+    for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+        assert want["counters"][k] == getattr(c, k), k
+    if n_tris >= 64:
+        assert c.shades > 200 and c.textured > 50, "the scene must exercise shading and textures"
+
+
+def test_duplicate_triangles_resolve_ties_like_the_oracle(oracle):
+    """Two coincident triangles with different materials: the hit must go to the one the reference's
+    traversal order finds first (strict <), so the image differs if the two are swapped."""
+    import ctypes as C
+    import raytracing_c_amd as rt
+    from tests import _oracle
+    from tests.test_gpu_parity import _rays_for
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    hs = make_scene(11, 40)
+    rng = np.random.default_rng(0)
+    n = 20000
+    rays = _rays_for(hs, n, rng)
+    wt, wtri, wuv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
+    oracle.oracle_trace_rays(C.byref(hs.scene), n, rays.ctypes.data, wt.ctypes.data, wtri.ctypes.data, wuv.ctypes.data)
+    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    assert d, rt.last_error()
+    try:
+        gt, gtri, guv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
+        assert rt.lib.rt_test_trace(d, n, rays.ctypes.data, gt.ctypes.data, gtri.ctypes.data, guv.ctypes.data) == 0
+    finally:
+        rt.lib.rt_scene_release(d)
+    assert np.array_equal(wtri, gtri) and np.array_equal(wt.view(np.uint32), gt.view(np.uint32))
+    # ties really occur: some hit triangle has an exact duplicate elsewhere in the triangle block
+    soa = hs.soa_array().T                           # (slots, 9)
+    hit_ids = np.unique(wtri[wtri >= 0])
+    dup = 0
+    for t in hit_ids:
+        same = np.nonzero((soa == soa[t]).all(axis=1))[0]
+        dup += len(same) > 1
+    assert dup >= 2
