@@ -121,6 +121,10 @@ def measured_traffic(workload):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL prints its
+    # version block there at communicator creation) are sent to stderr for the whole run.
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,7 +152,13 @@ def main():
     if rt.lib.rt_init(local_rank) != 0:
         raise RuntimeError("rt_init: " + rt.last_error())
     dist = None
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("RT_BENCH_FORCE_DIST") == "1"     # rehearsal: RCCL path with one rank
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -177,7 +187,8 @@ def main():
     accum = torch.zeros((h, w, 3), dtype=torch.int64, device=dev)
     image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
     tiles = torch.zeros((max_local, 1024 * 3), dtype=torch.uint8, device=dev)
-    all_tiles = torch.zeros((world, max_local, 1024 * 3), dtype=torch.uint8, device=dev) if world > 1 else None
+    multi = world > 1 or force_dist
+    all_tiles = torch.zeros((world, max_local, 1024 * 3), dtype=torch.uint8, device=dev) if multi else None
     host_image = torch.zeros((h, w, 3), dtype=torch.uint8).pin_memory()
     params = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, rank, world, args.slab, 0)
 
@@ -186,7 +197,7 @@ def main():
         accum.zero_()
         if rt.lib.rt_render_accumulate(dscene, C.byref(params), accum.data_ptr(), stream) != 0:
             raise RuntimeError(rt.last_error())
-        if world == 1:
+        if not multi:
             if rt.lib.rt_resolve(C.byref(params), accum.data_ptr(), None, image.data_ptr(), None, stream) != 0:
                 raise RuntimeError(rt.last_error())
         else:
@@ -283,7 +294,8 @@ def main():
         if args.save:
             from PIL import Image
             Image.fromarray(host_image.numpy()).save(args.save)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     rt.lib.rt_scene_release(dscene)
     if dist is not None:
