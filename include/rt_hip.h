@@ -123,6 +123,10 @@ extern int rt_render_frame(Scene const *scene, Image const *image, isize samples
  * (read back synchronously). */
 extern int rt_get_counters(RT_Counters *out);
 
+/* Diagnostic kernel only (env RT_KERNEL=4): 8 pairs (times a block ran, lanes it ran with) for
+ * shade, environment, regenerate, leaf (uniform), leaf (per lane), node (uniform), node (per lane), pop. */
+extern int rt_get_sched_stats(u64 out[16]);
+
 /* GPU time of the most recent path-tracing kernel launch in milliseconds
  * (HIP events on the launch stream); negative if none.  Synchronises. */
 extern f32 rt_last_kernel_ms(void);

@@ -505,6 +505,11 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   }
   K.sched_split = 0;     // measured on helmet 1080p: one combined block at 48 lanes beats every split setting by 2-4 %
   if (const char *e = getenv("RT_SCHED_SPLIT")) K.sched_split = atoi(e) != 0;
+  K.pop_iters = 1 << 30;     // measured: resolving every pop before the next block (56.8 ms) beats 1 (65.7), 2 (59.3), 4 (57.1) rounds
+  if (const char *e = getenv("RT_POP_ITERS")) {
+    int v = atoi(e);
+    if (v >= 1) K.pop_iters = v;
+  }
   K.sched_thresh_shade = 24;
   if (const char *e = getenv("RT_SCHED_THRESH_SHADE")) {
     int v = atoi(e);
@@ -519,7 +524,7 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   if (variant == 2) {
     smem = 4 * per_wave;
   } else if (variant != 1) {
-    variant = 3;
+    if (variant != 4) variant = 3;
     int room = (lds_limit - 16 * per_wave) / 208;
     if (room < 0) room = 0;
     K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
@@ -682,6 +687,18 @@ static float timed_slot_ms(size_t slot) {
   float ms = -1.0f;
   if (hipEventElapsedTime(&ms, g_ws.ev0[slot], g_ws.ev1[slot]) != hipSuccess) return -1.0f;
   return ms;
+}
+
+// Block statistics of the diagnostic kernel (RT_KERNEL=4): 8 pairs (executions, lanes) for
+// shade, environment, regenerate, leaf-scalar, leaf-vector, node-scalar, node-vector, pop.
+extern "C" int rt_get_sched_stats(u64 out[16]) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0 || !out) return -1;
+  unsigned long long c[RT_N_COUNTERS];
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(c, g_ws.counters, sizeof c, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; i++) out[i] = c[8 + i];
+  return 0;
 }
 
 extern "C" f32 rt_last_kernel_ms(void) {

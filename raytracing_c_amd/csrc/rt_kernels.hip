@@ -813,7 +813,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
 #define PH_HIT  4     // traversal finished with a hit: wants shading
 #define PH_MISS 5     // traversal finished without a hit: wants the environment
 
-template <int WAVES, bool LDSN>
+template <int WAVES, bool LDSN, bool STATS>
 __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P) {
   // dynamic LDS: [ top of the BVH, n_lds_nodes x 13 float4 (LDSN only) ][ per wave: perm stack, depth x 64 u32 |
   //               accumulator tile, 64 pixels x 3 x u64 ]
@@ -848,6 +848,12 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
   const int leaf_level = P.depth - 1;
   const int thresh = P.sched_thresh;
   const int thresh_shade = P.sched_thresh_shade;
+  const int pop_iters = P.pop_iters;
+  // diagnostic build only (STATS): how often each block ran and with how many lanes; wave-uniform
+  uint32_t st[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) st[i] = 0;
+#define STAT(slot, lanes) do { if (STATS) { st[2 * (slot)] += 1; st[2 * (slot) + 1] += (uint32_t)(lanes); } } while (0)
 
   for (;;) {
     // ---- dequeue one work item (wave-uniform).  Items are small (8x8 pixels x 16 samples by default):
@@ -887,12 +893,13 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
       const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
       const int nH = (int)__popcll(__ballot(phase == PH_HIT));
       const int nE = (int)__popcll(__ballot(phase == PH_MISS || (can_regen && phase == PH_NEED)));
-      if (nN + nL + nH + nE == 0) break;          // every lane idle and the item has no paths left
+      const bool popping = __any(phase == PH_POP);   // lanes still between two traversal blocks (see the pop loop below)
+      if (nN + nL + nH + nE == 0 && !popping) break;          // every lane idle and the item has no paths left
 
       // Block choice.  Shading is by far the most expensive block (~2 200 VALU instructions against ~330 for
       // a node), so it gets its own threshold: it runs when thresh_shade lanes wait for it; environment +
       // regeneration (~750) when thresh lanes wait; traversal otherwise; with nothing traversing, whatever waits.
-      const bool traversing = nN + nL > 0;
+      const bool traversing = nN + nL > 0 || popping;
       bool run_shade, run_env;
       if (P.sched_split) {
         run_shade = nH > 0 && (nH >= thresh_shade || (!traversing && nE < thresh));
@@ -904,6 +911,9 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
       }
 
       if (run_shade || run_env) {
+        if (run_shade) STAT(0, nH);
+        if (run_env) STAT(1, __popcll(__ballot(phase == PH_MISS)));
+        if (run_env && can_regen) STAT(2, __popcll(__ballot(phase == PH_NEED)));
         bool  done = false, start = false;
         rt_v3 radiance = rt_v3_make(0, 0, 0);
         rt_v3 org = ray.o, dir = ray.d;
@@ -963,15 +973,17 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
         continue;
       }
 
-    if (nL >= nN) {
+    if (nN + nL == 0) {
+        // only lanes between blocks: fall through to the pop loop
+      } else if (nL >= nN) {
         // ================= LEAF =================
         if (phase == PH_LEAF) {
           cn.leaves += 1;
           int  g = child - P.last_row_offset;
           int  g0 = __builtin_amdgcn_readfirstlane(g);
           bool got;
-          if (__ballot(g != g0) == 0) got = leaf_test<true>(P, ray, g0, hit);     // all lanes on one leaf
-          else got = leaf_test<false>(P, ray, g, hit);
+          if (__ballot(g != g0) == 0) { STAT(3, nL); got = leaf_test<true>(P, ray, g0, hit); }     // all lanes on one leaf
+          else { STAT(4, nL); got = leaf_test<false>(P, ray, g, hit); }
           if (got) dirty = 0xFFFFFFFFu;
           phase = PH_POP;
         }
@@ -985,9 +997,9 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
           cn.nodes += 1;
           int n0 = __builtin_amdgcn_readfirstlane(node);
           if (all_fast) {
-            if (__ballot(node != n0) == 0) cur = node_enter<true, NODE_SCALAR>(P, ray, n0, hit.t, lds_nodes);   // all lanes on one node
-            else if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes);
-            else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+            if (__ballot(node != n0) == 0) { STAT(5, nN); cur = node_enter<true, NODE_SCALAR>(P, ray, n0, hit.t, lds_nodes); }   // all lanes on one node
+            else if (LDSN && __ballot(node >= n_lds) == 0) { STAT(6, nN); cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes); }
+            else { STAT(6, nN); cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes); }
           } else {
             cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
           }
@@ -996,8 +1008,11 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
         }
       }
 
-      // ---- pops: cheap, run until every traversing lane wants a NODE, a LEAF or is finished ----
-      while (__any(phase == PH_POP)) {
+      // ---- pops: after a block, at most pop_iters rounds of "take the next child / go up one level"; a lane that
+      //      needs more (several levels up, rejected children) stays in PH_POP and continues after the next block,
+      //      instead of making the whole wave spin with two dozen lanes ----
+      for (int it = 0; it < pop_iters && __any(phase == PH_POP); it++) {
+        STAT(7, __popcll(__ballot(phase == PH_POP)));
         if (phase == PH_POP) {
           uint32_t cnt = cur >> 24;
           if (cnt == 0 || level < 0) {
@@ -1050,7 +1065,12 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
     atomicAdd(P.counters + CNT_SHADES, (unsigned long long)c4);
     atomicAdd(P.counters + CNT_BG, (unsigned long long)c5);
     atomicAdd(P.counters + CNT_TEXTURED, (unsigned long long)c6);
+    if (STATS) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) atomicAdd(P.counters + 8 + i, (unsigned long long)st[i]);
+    }
   }
+#undef STAT
 }
 
 // ---------------------------------------------------------------------------------
@@ -1295,16 +1315,22 @@ extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int varia
   if (variant == 1) {
     hipLaunchKernelGGL(rt_path_kernel, dim3((n_waves + 3) / 4), dim3(RT_BLOCK_THREADS), 0, stream, *P);
   } else if (variant == 2) {
-    hipLaunchKernelGGL((rt_path_kernel_sched<4, false>), dim3((n_waves + 3) / 4), dim3(256), smem_bytes, stream, *P);
+    hipLaunchKernelGGL((rt_path_kernel_sched<4, false, false>), dim3((n_waves + 3) / 4), dim3(256), smem_bytes, stream, *P);
   } else {
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<16, true>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<16, true, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<16, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL((rt_path_kernel_sched<16, true>), dim3((n_waves + 15) / 16), dim3(1024), smem_bytes, stream, *P);
+    if (variant == 4)    // diagnostic build: same kernel plus block-execution statistics in counters[8..23]
+      hipLaunchKernelGGL((rt_path_kernel_sched<16, true, true>), dim3((n_waves + 15) / 16), dim3(1024), smem_bytes, stream, *P);
+    else
+      hipLaunchKernelGGL((rt_path_kernel_sched<16, true, false>), dim3((n_waves + 15) / 16), dim3(1024), smem_bytes, stream, *P);
   }
   return (int)hipGetLastError();
 }

@@ -57,6 +57,14 @@ def main():
                 print(f"thresh_shade {ts:2d} thresh {th:2d}: {run(16, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_SCHED_THRESH_SHADE")
         os.environ.pop("RT_SCHED_THRESH")
+    if "pop" in knobs:
+        for pi in (1, 2, 3, 4, 6, 100):
+            os.environ["RT_POP_ITERS"] = str(pi)
+            for th in (40, 48, 56):
+                os.environ["RT_SCHED_THRESH"] = str(th)
+                print(f"pop_iters {pi:3d} thresh {th}: {run(16, 4):8.3f} ms", flush=True)
+        os.environ.pop("RT_POP_ITERS")
+        os.environ.pop("RT_SCHED_THRESH")
     if "map" in knobs:
         for sm in (0, 1):
             os.environ["RT_SAMPLE_MAJOR"] = str(sm)
