@@ -9,10 +9,15 @@
  * unpinned.  This header defines it ONCE, using only
  * operations that IEEE-754 rounds identically on x86-64 and gfx950:
  *   + - * /  sqrt  floor  int<->float conversion  comparisons  bit casts.
- * Both compilers MUST be run with -ffp-contract=off and without fast-math
- * (hipcc additionally keeps its default correctly rounded fp32 divide/sqrt);
- * then every function below returns bit-identical results on CPU and GPU, which
- * is what lets tests/ demand bit-exact images instead of a tolerance.
+ * plus EXPLICIT fused multiply-adds (rt_fmaf = fmaf, one rounding, identical on
+ * x86-64 FMA units and gfx950 v_fma_f32) inside the polynomial kernels of the
+ * elementary functions only -- they replace libm calls, so there is no reference
+ * operation order to preserve there, and Horner steps cost one instruction
+ * instead of two.  Both compilers MUST be run with -ffp-contract=off (no
+ * IMPLICIT contraction anywhere) and without fast-math (hipcc additionally
+ * keeps its default correctly rounded fp32 divide/sqrt); then every function
+ * below returns bit-identical results on CPU and GPU, which is what lets tests/
+ * demand bit-exact images instead of a tolerance.
  *
  * Polynomial coefficients are the classic single-precision minimax sets
  * (Cephes, S. Moshier) for log/exp/sin/cos/atan/asin.
@@ -49,6 +54,7 @@ RT_FN float rt_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > h
 RT_FN float rt_absf(float x) { return rt_u2f(rt_f2u(x) & 0x7fffffffu); }
 RT_FN float rt_sqrtf(float x) { return __builtin_sqrtf(x); }
 RT_FN float rt_floorf(float x) { return __builtin_floorf(x); }
+RT_FN float rt_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   /* a*b+c, ONE rounding */
 RT_FN float rt_fractf(float x) { return x - rt_floorf(x); }   /* raytracer.c:582 */
 
 /* ---- RNG (common.h:13-24) --------------------------------------------------- */
@@ -120,36 +126,36 @@ RT_FN float rt_logf(float x) {
   if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
   float z = m * m;
   float y = 7.0376836292E-2f;
-  y = y * m + -1.1514610310E-1f;
-  y = y * m +  1.1676998740E-1f;
-  y = y * m + -1.2420140846E-1f;
-  y = y * m +  1.4249322787E-1f;
-  y = y * m + -1.6668057665E-1f;
-  y = y * m +  2.0000714765E-1f;
-  y = y * m + -2.4999993993E-1f;
-  y = y * m +  3.3333331174E-1f;
+  y = rt_fmaf(y, m, -1.1514610310E-1f);
+  y = rt_fmaf(y, m,  1.1676998740E-1f);
+  y = rt_fmaf(y, m, -1.2420140846E-1f);
+  y = rt_fmaf(y, m,  1.4249322787E-1f);
+  y = rt_fmaf(y, m, -1.6668057665E-1f);
+  y = rt_fmaf(y, m,  2.0000714765E-1f);
+  y = rt_fmaf(y, m, -2.4999993993E-1f);
+  y = rt_fmaf(y, m,  3.3333331174E-1f);
   y = y * m * z;
   float fe = (float)e;
-  y = y + -2.12194440e-4f * fe;
-  y = y + -0.5f * z;
+  y = rt_fmaf(-2.12194440e-4f, fe, y);
+  y = rt_fmaf(-0.5f, z, y);
   float r = m + y;
-  r = r + 0.693359375f * fe;
+  r = rt_fmaf(0.693359375f, fe, r);
   return r;
 }
 
 /* e^x for |x| < 87 */
 RT_FN float rt_expf(float x) {
-  float n = rt_floorf(1.44269504088896341f * x + 0.5f);
-  float r = x - n * 0.693359375f;
-  r = r - n * -2.12194440e-4f;
+  float n = rt_floorf(rt_fmaf(1.44269504088896341f, x, 0.5f));
+  float r = rt_fmaf(n, -0.693359375f, x);
+  r = rt_fmaf(n, 2.12194440e-4f, r);
   float z = r * r;
   float p = 1.9875691500E-4f;
-  p = p * r + 1.3981999507E-3f;
-  p = p * r + 8.3334519073E-3f;
-  p = p * r + 4.1665795894E-2f;
-  p = p * r + 1.6666665459E-1f;
-  p = p * r + 5.0000001201E-1f;
-  p = p * z + r + 1.0f;
+  p = rt_fmaf(p, r, 1.3981999507E-3f);
+  p = rt_fmaf(p, r, 8.3334519073E-3f);
+  p = rt_fmaf(p, r, 4.1665795894E-2f);
+  p = rt_fmaf(p, r, 1.6666665459E-1f);
+  p = rt_fmaf(p, r, 5.0000001201E-1f);
+  p = rt_fmaf(p, z, r) + 1.0f;
   int   in = (int)n;
   float sc = rt_u2f((uint32_t)(in + 127) << 23);
   return p * sc;
@@ -168,11 +174,14 @@ RT_FN void rt_sincosf(float x, float *s, float *c) {
   int q = (int)(x * 1.27323954473516f);       /* x * 4/pi, truncated */
   q += q & 1;
   float y = (float)q;
-  float r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+  float r = rt_fmaf(y, -0.78515625f, x);
+  r = rt_fmaf(y, -2.4187564849853515625e-4f, r);
+  r = rt_fmaf(y, -3.77489497744594108e-8f, r);
   float z = r * r;
-  float ps = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * r + r;
-  float pc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z
-             - 0.5f * z + 1.0f;
+  float ps = rt_fmaf(rt_fmaf(-1.9515295891E-4f, z, 8.3321608736E-3f), z, -1.6666654611E-1f);
+  ps = rt_fmaf(ps * z, r, r);
+  float pc = rt_fmaf(rt_fmaf(2.443315711809948E-005f, z, -1.388731625493765E-003f), z, 4.166664568298827E-002f);
+  pc = rt_fmaf(pc * z, z, rt_fmaf(-0.5f, z, 1.0f));
   int k = (q >> 1) & 3;                        /* x = k*pi/2 + r */
   float ss = (k & 1) ? pc : ps;
   float cc = (k & 1) ? ps : pc;
@@ -187,8 +196,8 @@ RT_FN float rt_atanf_pos(float a) {            /* a >= 0 */
   if (a > 2.414213562373095f) { yb = 1.5707963267948966192f; a = -(1.0f / a); }
   else if (a > 0.4142135623730950f) { yb = 0.7853981633974483096f; a = (a - 1.0f) / (a + 1.0f); }
   float z = a * a;
-  float p = ((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f;
-  return yb + (p * z * a + a);
+  float p = rt_fmaf(rt_fmaf(rt_fmaf(8.05374449538e-2f, z, -1.38776856032E-1f), z, 1.99777106478E-1f), z, -3.33329491539E-1f);
+  return yb + rt_fmaf(p * z, a, a);
 }
 
 RT_FN float rt_atan2f(float y, float x) {
@@ -214,8 +223,9 @@ RT_FN float rt_asinf(float x) {
   int   big = a > 0.5f;
   float z, w;
   if (big) { z = 0.5f * (1.0f - a); w = rt_sqrtf(z); } else { w = a; z = a * a; }
-  float p = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z + 7.4953002686E-2f) * z
-             + 1.6666752422E-1f) * z * w + w;
+  float p = rt_fmaf(rt_fmaf(rt_fmaf(rt_fmaf(4.2163199048E-2f, z, 2.4181311049E-2f), z, 4.5470025998E-2f), z, 7.4953002686E-2f),
+                    z, 1.6666752422E-1f);
+  p = rt_fmaf(p * z, w, w);
   if (big) p = 1.5707963267948966192f - (p + p);
   return x < 0.0f ? -p : p;
 }

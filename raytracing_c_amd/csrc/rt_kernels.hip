@@ -882,7 +882,7 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
     ray_setup(ray, rt_v3_make(0, 0, 0), rt_v3_make(0, 0, 1));
     rt_v3 tint = rt_v3_make(1, 1, 1), emis = rt_v3_make(0, 0, 0);
     int   level = -1, node = 0, child = 0;
-    uint32_t cur = 0, dirty = 0;
+    uint32_t cur = 0, dirty = 0, live = 0;     // live: bit L set <=> the perm word stored for level L still has children
     HitRec hit;
     hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
     int next_k = 0;      // wave-uniform
@@ -964,6 +964,7 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
           hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
           cn.rays += 1;
           dirty = 0;
+          live = 0;
           cur = 0;
           level = -1;
           node = 0;
@@ -991,7 +992,10 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
         // ================= NODE =================
         const bool all_fast = __ballot(phase == PH_NODE && !ray.fast) == 0;
         if (phase == PH_NODE) {
-          if (level >= 0) perm[level * 64 + lane] = cur;
+          if (level >= 0) {
+            perm[level * 64 + lane] = cur;
+            live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
+          }
           node = child;
           level += 1;
           cn.nodes += 1;
@@ -1016,10 +1020,19 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
         if (phase == PH_POP) {
           uint32_t cnt = cur >> 24;
           if (cnt == 0 || level < 0) {
-            level -= 1;
-            node = (node - 1) >> 3;
-            if (level >= 0) cur = perm[level * 64 + lane];
-            else phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
+            // go up to the nearest level that still has children to visit -- in one step: the k-th ancestor of
+            // node n in the implicit 8-ary tree is (n - (8^k - 1)/7) >> 3k, and (8^k - 1)/7 is k ones 3 bits apart
+            uint32_t above = (level > 0) ? (live & ((1u << level) - 1u)) : 0u;
+            if (above == 0u) {
+              level = -1;
+              phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
+            } else {
+              int target = 31 - __clz((int)above);
+              int k3 = 3 * (level - target);
+              node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
+              level = target;
+              cur = perm[level * 64 + lane];
+            }
           } else {
             int j = (int)(cur & 7u);
             cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
