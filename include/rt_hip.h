@@ -126,6 +126,8 @@ extern int rt_get_counters(RT_Counters *out);
 /* Diagnostic kernel only (env RT_KERNEL=4): 8 pairs (times a block ran, lanes it ran with) for
  * shade, environment, regenerate, leaf (uniform), leaf (per lane), node (uniform), node (per lane), pop. */
 extern int rt_get_sched_stats(u64 out[16]);
+/* ... and per wave (start tick, end tick, items) of the last diagnostic launch; ticks are 10 ns.  Returns the wave count. */
+extern int rt_get_wave_times(u64 *out, i32 max_waves);
 
 /* GPU time of the most recent path-tracing kernel launch in milliseconds
  * (HIP events on the launch stream); negative if none.  Synchronises. */

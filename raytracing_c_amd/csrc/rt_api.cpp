@@ -32,6 +32,7 @@ int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *o
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
 int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int lw, int lh, int stride, int comp,
                        int samples, int *owner, uint8_t *pixels, hipStream_t stream);
+int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
 }
@@ -90,6 +91,8 @@ struct Workspace {
   // HIP event pairs around every path-kernel launch since the last timing reset
   std::vector<hipEvent_t> ev0, ev1;
   size_t              n_timed = 0;
+  unsigned long long *wave_times = nullptr;   // diagnostic kernel (RT_KERNEL=4)
+  int                 wave_times_n = 0;
 };
 #define RT_MAX_TIMED 256
 static Workspace g_ws;
@@ -159,6 +162,12 @@ struct RT_Device_Scene {
   // fingerprint of the host scene this was built from
   const void  *fp_nodes = nullptr, *fp_tris = nullptr, *fp_bg = nullptr;
   int64_t      fp_len = 0, fp_depth = 0;
+  // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
+  uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
+  uint32_t    *order = nullptr, *hist = nullptr;
+  int32_t      sched_tiles = 0, sched_cur = 0;
+  bool         sched_valid = false;            // cost[cur^1] holds the costs of a launch with sched_key
+  uint64_t     sched_key = 0;
 };
 
 static std::unordered_map<const Scene *, RT_Device_Scene *> g_scene_cache;
@@ -462,7 +471,13 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   K->sample_first = p->sample_first;
   K->sample_end = p->sample_count > 0 ? p->sample_first + p->sample_count : p->samples;
   int n_samples = K->sample_end - K->sample_first;
-  int slab = p->slab > 0 ? p->slab : 16;
+  // samples per work item: 16, or 8 when that would leave fewer than 32 items per wave (a rank of an 8-GPU
+  // partition, or a low-spp frame): measured on 1/8 of the helmet frame 8.3 ms against 8.7 (16) and 9.7 (4)
+  int slab = p->slab;
+  if (slab <= 0) {
+    int64_t items16 = (int64_t)K->n_local_chunks * 16 * ((n_samples + 15) / 16);
+    slab = (items16 < (int64_t)32 * g_num_cus * 16) ? 8 : 16;
+  }
   int shift = 0;
   while ((1 << shift) < slab && (1 << shift) < n_samples) shift++;
   K->slab_shift = shift;
@@ -534,6 +549,53 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     }
     smem = K.n_lds_nodes * 208 + 16 * per_wave;
   }
+  // ---- schedule feedback (phase-scheduled kernels only): visit expensive tiles first ----
+  K.order = nullptr;
+  K.tile_cost = nullptr;
+  const char *order_mode = getenv("RT_ORDER");           // "lpt" (default) | "identity"
+  if (variant != 1 && !(order_mode && strcmp(order_mode, "identity") == 0)) {
+    int n_tiles = K.n_local_chunks * 16;
+    // the costs of a launch are reusable by a launch of the same view, partition and bounce limit
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](const void *ptr, size_t n) {
+      const unsigned char *b = (const unsigned char *)ptr;
+      for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; }
+    };
+    mix(K.cam, sizeof K.cam);
+    mix(&K.focal_length, sizeof K.focal_length);
+    int32_t ids[6] = {K.width, K.height, K.rank, K.world, K.max_bounces, n_tiles};
+    mix(ids, sizeof ids);
+    if (d->sched_tiles != n_tiles) {
+      (void)hipFree(d->cost[0]); (void)hipFree(d->cost[1]); (void)hipFree(d->order); (void)hipFree(d->hist);
+      d->cost[0] = d->cost[1] = d->order = d->hist = nullptr;
+      d->sched_tiles = 0;
+      d->sched_valid = false;
+      HIP_TRY(hipMalloc(&d->cost[0], (size_t)n_tiles * 4));
+      HIP_TRY(hipMalloc(&d->cost[1], (size_t)n_tiles * 4));
+      HIP_TRY(hipMalloc(&d->order, (size_t)n_tiles * 4));
+      HIP_TRY(hipMalloc(&d->hist, 1024));
+      d->sched_tiles = n_tiles;
+    }
+    if (d->sched_valid && d->sched_key == key) {
+      int rc2 = rt_launch_tile_order(n_tiles, d->cost[d->sched_cur ^ 1], d->hist, d->order, stream);
+      if (rc2 != 0) return rt_fail("tile order kernels failed: %s", hipGetErrorString((hipError_t)rc2));
+      K.order = d->order;
+    }
+    HIP_TRY(hipMemsetAsync(d->cost[d->sched_cur], 0, (size_t)n_tiles * 4, stream));
+    K.tile_cost = d->cost[d->sched_cur];
+    d->sched_cur ^= 1;                // after this launch, cost[sched_cur ^ 1] is the buffer just written
+    d->sched_key = key;
+    d->sched_valid = true;
+  }
+
+  K.wave_times = nullptr;
+  if (variant == 4) {
+    if (!g_ws.wave_times) HIP_TRY(hipMalloc(&g_ws.wave_times, (size_t)65536 * 3 * 8));
+    HIP_TRY(hipMemsetAsync(g_ws.wave_times, 0, (size_t)65536 * 3 * 8, stream));
+    K.wave_times = g_ws.wave_times;
+    g_ws.wave_times_n = n_waves;
+  }
+
   size_t slot = g_ws.n_timed % RT_MAX_TIMED;
   if (slot >= g_ws.ev0.size()) {
     hipEvent_t a, b;
@@ -699,6 +761,16 @@ extern "C" int rt_get_sched_stats(u64 out[16]) {
   HIP_TRY(hipMemcpy(c, g_ws.counters, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; i++) out[i] = c[8 + i];
   return 0;
+}
+
+// Diagnostic kernel (RT_KERNEL=4): per wave start time, end time (100 MHz ticks) and items processed.
+extern "C" int rt_get_wave_times(u64 *out, i32 max_waves) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0 || !out || !g_ws.wave_times) return -1;
+  int n = g_ws.wave_times_n < max_waves ? g_ws.wave_times_n : max_waves;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, g_ws.wave_times, (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
+  return n;
 }
 
 extern "C" f32 rt_last_kernel_ms(void) {

@@ -850,6 +850,8 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
   const int thresh_shade = P.sched_thresh_shade;
   const int pop_iters = P.pop_iters;
   // diagnostic build only (STATS): how often each block ran and with how many lanes; wave-uniform
+  const unsigned long long t_wave_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
+  uint32_t n_items_done = 0;
   uint32_t st[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) st[i] = 0;
@@ -866,13 +868,17 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
     if (w >= (uint32_t)P.n_work) break;
 
     const int slab_idx = (int)(w % (uint32_t)P.n_slabs);
-    const int tile_idx = (int)(w / (uint32_t)P.n_slabs);
+    // tiles are visited in the order the host prepared: most expensive first (cost = rays the tile needed in
+    // the previous launch of this view), so that the last items of the launch are cheap ones
+    const int tile_pos = (int)(w / (uint32_t)P.n_slabs);
+    const int tile_idx = P.order ? (int)P.order[tile_pos] : tile_pos;
     const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
     const int chunk = lchunk * P.world + P.rank;
     const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
     const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
     if (tile_x0 >= P.width || tile_y0 >= P.height) continue;
     const int s_base = slab_idx << P.slab_shift;
+    const uint32_t rays_before = cn.rays;
 
     // ---- per-lane state ----
     int   phase = PH_NEED;
@@ -1066,6 +1072,11 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
         atomicAdd(dst + 2, b);
       }
     }
+    if (STATS) n_items_done += 1;
+    if (P.tile_cost) {          // rays this item needed: the next launch of the same view schedules by it
+      uint32_t r = wave_sum(cn.rays - rays_before);
+      if (lane == 0) atomicAdd(&P.tile_cost[tile_idx], r);
+    }
   }
 
   uint32_t c0 = wave_sum(cn.paths), c1 = wave_sum(cn.rays), c2 = wave_sum(cn.nodes), c3 = wave_sum(cn.leaves);
@@ -1081,6 +1092,12 @@ __global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P)
     if (STATS) {
 #pragma unroll
       for (int i = 0; i < 16; i++) atomicAdd(P.counters + 8 + i, (unsigned long long)st[i]);
+      if (P.wave_times) {
+        int wid = blockIdx.x * WAVES + wave;
+        P.wave_times[wid * 3 + 0] = t_wave_start;
+        P.wave_times[wid * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+        P.wave_times[wid * 3 + 2] = n_items_done;
+      }
     }
   }
 #undef STAT
@@ -1261,6 +1278,46 @@ extern "C" int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n
   int n = lw * lh;
   hipLaunchKernelGGL(rt_lightmap_bake_kernel, dim3((n + RT_BLOCK_THREADS - 1) / RT_BLOCK_THREADS), dim3(RT_BLOCK_THREADS), 0,
                      stream, *P, verts, lw, lh, stride, comp, samples, owner, pixels);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Tile order for the next launch: counting sort of the tiles by descending cost bucket (4 buckets per
+// power of two of last launch's ray count).  Order inside a bucket is whatever the atomics give: only the
+// schedule depends on it, never a pixel (order-free accumulation).
+#define RT_ORDER_BUCKETS 132
+__device__ __forceinline__ int cost_bucket(uint32_t c) {
+  if (c < 4u) return (int)c;                               // 0..3
+  int e = 31 - __clz((int)c);                              // >= 2
+  return 4 * (e - 1) + (int)((c >> (e - 2)) & 3u);         // 4..131, monotonic in c
+}
+
+__global__ void rt_order_hist_kernel(int n, const uint32_t *cost, uint32_t *hist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+}
+
+__global__ void rt_order_scan_kernel(uint32_t *hist) {      // one thread: start offset of every bucket, expensive first
+  uint32_t run = 0;
+  for (int b = RT_ORDER_BUCKETS - 1; b >= 0; b--) {
+    uint32_t c = hist[b];
+    hist[b] = run;
+    run += c;
+  }
+}
+
+__global__ void rt_order_scatter_kernel(int n, const uint32_t *cost, uint32_t *cursor, uint32_t *order) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) order[atomicAdd(&cursor[cost_bucket(cost[i])], 1u)] = (uint32_t)i;
+}
+
+extern "C" int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(hist, 0, RT_ORDER_BUCKETS * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return (int)e;
+  int blocks = (n_tiles + 255) / 256;
+  hipLaunchKernelGGL(rt_order_hist_kernel, dim3(blocks), dim3(256), 0, stream, n_tiles, cost, hist);
+  hipLaunchKernelGGL(rt_order_scan_kernel, dim3(1), dim3(1), 0, stream, hist);
+  hipLaunchKernelGGL(rt_order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, n_tiles, cost, hist, order);
   return (int)hipGetLastError();
 }
 

@@ -99,6 +99,7 @@ def _declare(d):
     d.rt_render_frame.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, vp, vp]
     d.rt_get_counters.argtypes = [P(abi.RT_Counters)]
     d.rt_get_sched_stats.argtypes = [vp]
+    d.rt_get_wave_times.argtypes = [vp, C.c_int32]
     d.rt_last_kernel_ms.restype = C.c_float
     d.rt_kernel_timing_reset.restype = None
     d.rt_kernel_timing_mean_ms.argtypes = [P(C.c_int32)]
