@@ -51,7 +51,8 @@ def make_scene(seed, n_tris, depth_hint=None):
     return build_scene(P, N, UV, ids, mats, images, cam, 0.9, bg)
 
 
-@pytest.mark.parametrize("seed,n_tris", [(1, 5), (2, 8), (3, 9), (4, 64), (5, 65), (6, 400), (7, 513), (8, 3000)])
+@pytest.mark.parametrize("seed,n_tris", [(1, 5), (2, 8), (3, 9), (4, 64), (5, 65), (6, 400), (7, 513), (8, 3000),
+                                         (9, 40000)])      # 40 000 triangles: depth 5, 4 681 nodes -- more than the LDS copy holds
 def test_random_scene_bit_exact(oracle, seed, n_tris):
     import raytracing_c_amd as rt
     from tests import _oracle
@@ -65,6 +66,8 @@ def test_random_scene_bit_exact(oracle, seed, n_tris):
     c = got["counters"]
     for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
         assert want["counters"][k] == getattr(c, k), k
+    if n_tris == 40000:
+        assert hs.depth == 5 and hs.n_nodes == 4681
     if n_tris >= 64:
         assert c.shades > 200 and c.textured > 50, "the scene must exercise shading and textures"
 
