@@ -1292,9 +1292,17 @@ __device__ __forceinline__ int cost_bucket(uint32_t c) {
   return 4 * (e - 1) + (int)((c >> (e - 2)) & 3u);         // 4..131, monotonic in c
 }
 
+// (most tiles of a frame fall into a handful of buckets: the counters are combined per workgroup in LDS first,
+//  one global atomic per bucket and workgroup -- a global atomic per tile serialises on those few addresses)
 __global__ void rt_order_hist_kernel(int n, const uint32_t *cost, uint32_t *hist) {
+  __shared__ uint32_t local[RT_ORDER_BUCKETS];
+  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x) local[b] = 0;
+  __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+  if (i < n) atomicAdd(&local[cost_bucket(cost[i])], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x)
+    if (local[b]) atomicAdd(&hist[b], local[b]);
 }
 
 __global__ void rt_order_scan_kernel(uint32_t *hist) {      // one thread: start offset of every bucket, expensive first
@@ -1307,8 +1315,21 @@ __global__ void rt_order_scan_kernel(uint32_t *hist) {      // one thread: start
 }
 
 __global__ void rt_order_scatter_kernel(int n, const uint32_t *cost, uint32_t *cursor, uint32_t *order) {
+  __shared__ uint32_t local[RT_ORDER_BUCKETS], base[RT_ORDER_BUCKETS];
+  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x) local[b] = 0;
+  __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) order[atomicAdd(&cursor[cost_bucket(cost[i])], 1u)] = (uint32_t)i;
+  int bucket = 0;
+  uint32_t pos = 0;
+  if (i < n) {
+    bucket = cost_bucket(cost[i]);
+    pos = atomicAdd(&local[bucket], 1u);                   // rank inside this workgroup's share of the bucket
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x)
+    base[b] = local[b] ? atomicAdd(&cursor[b], local[b]) : 0u;   // reserve the workgroup's range once per bucket
+  __syncthreads();
+  if (i < n) order[base[bucket] + pos] = (uint32_t)i;
 }
 
 extern "C" int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream) {
