@@ -16,7 +16,7 @@ def main(tag):
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     lines = [f"# rocprofv3 summary `{tag}` -- bench.py (helmet 1920x1080, 256 spp, 8 bounces, 1 x MI355X)", ""]
-    stats = glob.glob(os.path.join(src, f"prof_{tag}_stats", "*", "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, f"prof_{tag}_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]
     kernel_avg_ms = None
     if stats:
         lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1`", "",
@@ -40,7 +40,12 @@ def main(tag):
                       + (f" vs rocprof average {kernel_avg_ms:.3f}" if kernel_avg_ms else ""), ""]
     counters = collections.OrderedDict()
     meta = {}
-    for f in sorted(glob.glob(os.path.join(src, f"prof_{tag}_pmc_*", "*", "*_counter_collection.csv"))):
+    newest = {}
+    for f in glob.glob(os.path.join(src, f"prof_{tag}_pmc_*", "*", "*_counter_collection.csv")):
+        key = f.split(os.sep)[-3]            # one pass directory may hold the files of several gpurun calls: newest wins
+        if key not in newest or os.path.getmtime(f) > os.path.getmtime(newest[key]):
+            newest[key] = f
+    for f in sorted(newest.values()):
         for r in csv.DictReader(open(f)):
             if "rt_path_kernel" in r["Kernel_Name"]:
                 counters[r["Counter_Name"]] = counters.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
