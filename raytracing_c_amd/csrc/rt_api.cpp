@@ -458,6 +458,13 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 4; j++) K->cam[i][j] = cam->view_matrix.rows[i][j];
   K->focal_length = cam->focal_length;
+  {
+    volatile float fw = (float)p->width, fh = (float)p->height;      // plain IEEE fp32 divisions, as the kernel used to do
+    volatile float iw = 1.0f / fw, ih = 1.0f / fh, asp = fw / fh;
+    K->inv_width = iw;
+    K->inv_height = ih;
+    K->aspect = asp;
+  }
   K->width = p->width;
   K->height = p->height;
   K->samples = p->samples;

@@ -70,6 +70,7 @@ typedef struct {
   /* camera: rows 0..2 of view_matrix (rotation | translation), focal length */
   float cam[3][4];
   float focal_length;
+  float inv_width, inv_height, aspect;   /* 1/width, 1/height, width/height in fp32 (raytracer.c:615-617) */
   /* frame */
   int32_t width, height, samples, max_bounces;
   int32_t sample_first, sample_end;   /* this launch traces samples [first, end) of every pixel */

@@ -569,9 +569,11 @@ __device__ __forceinline__ void shade(const RT_KParams &P, int mat, const ShadeI
 // ---------------------------------------------------------------------------------
 // primary ray of (x, y, sample): raytracer.c:641-694 with exact 1/sqrt
 __device__ __forceinline__ void primary_ray(const RT_KParams &P, int x, int y, int sample, rt_v3 &o, rt_v3 &d) {
-  float inv_width = 1.0f / (float)P.width;
-  float inv_height = 1.0f / (float)P.height;
-  float aspect = (float)P.width / (float)P.height;
+  // 1/width, 1/height, width/height (raytracer.c:615-617) are frame constants: the host computes the same
+  // three fp32 divisions once (rt_api.cpp) instead of every lane for every path
+  float inv_width = P.inv_width;
+  float inv_height = P.inv_height;
+  float aspect = P.aspect;
   float jitter = rt_hash12((float)x * 50.0f + (float)sample, (float)y);
   float uvx = ((float)x + jitter - 0.5f) * 2.0f * inv_width - 1.0f;
   float uvy = ((float)y + jitter - 0.5f) * 2.0f * inv_height - 1.0f;
