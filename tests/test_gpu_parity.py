@@ -108,6 +108,37 @@ def test_trace_bit_exact(rt, oracle, asset):
     assert np.array_equal(_bits(wuv), _bits(guv))
 
 
+def test_leaf_known_answers_on_gpu(rt):
+    """The hand-derived cases of tests/test_oracle_kat.py::test_ray_triangles_hit_8_cases on the device:
+    closest of several, equal t -> LOWEST slot wins (min_f32x8, raytracer.c:27-29), t < eps and epsilon-padded
+    barycentric bounds (raytracer.c:137-149).  A <= 8 triangle scene is a depth-0 BVH: one leaf group, input order."""
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.loaders import camera_from_trs
+    from raytracing_c_amd.scene import Material, build_scene
+    tri = lambda z: [[0, 0, z], [1, 0, z], [0, 1, z]]          # noqa: E731
+    P = np.array([tri(5), tri(3), tri(3), tri(-1), tri(7), tri(4)], np.float32)
+    N = np.tile(np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32), (6, 1, 1))
+    UV = np.tile(np.array([[0, 0], [1, 0], [0, 1]], np.float32), (6, 1, 1))
+    hs = build_scene(P, N, UV, np.zeros(6, int), [Material()], [], camera_from_trs((0, 0, 9)), 1.0, procedural_background(16, 8))
+    assert hs.depth == 0 and hs.n_slots == 8
+    rays = np.array([[0.25, 0.25, 0, 0, 0, 1],          # hits z=3 twice (slots 1, 2), z=4, z=5, z=7 -> slot 1, t = 3
+                     [0.25, 0.25, 7.5, 0, 0, 1],        # everything behind the origin
+                     [-0.5e-4, 0.25, 0, 0, 0, 1],       # u = -0.5e-4: inside the epsilon padding
+                     [-2e-4, 0.25, 0, 0, 0, 1],         # u = -2e-4: outside
+                     [0.25, 0.25, 3.5, 0, 0, 1]], np.float32)   # starts between z=3 and z=4 -> slot 5 (z=4), t = 0.5
+    n = len(rays)
+    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    assert d, rt.last_error()
+    try:
+        t, tri_i, uv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
+        assert rt.lib.rt_test_trace(d, n, rays.ctypes.data, t.ctypes.data, tri_i.ctypes.data, uv.ctypes.data) == 0
+    finally:
+        rt.lib.rt_scene_release(d)
+    assert tri_i.tolist() == [1, -1, 1, -1, 5]
+    assert t[0] == 3.0 and np.isinf(t[1]) and t[2] == 3.0 and np.isinf(t[3]) and t[4] == 0.5
+    assert uv[0].tolist() == [0.25, 0.25]
+
+
 def test_texture_bit_exact(rt, oracle):
     from raytracing_c_amd.loaders import load_model
     hs = load_model(os.path.join(ASSETS, "helmet.glb"))
