@@ -546,16 +546,18 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   if (variant == 2) {
     smem = 4 * per_wave;
   } else if (variant != 1) {
+    const int waves_per_block = 16;
     if (variant != 4) variant = 3;
-    int room = (lds_limit - 16 * per_wave) / 208;
+    int room = (lds_limit - waves_per_block * per_wave) / 208;
     if (room < 0) room = 0;
     K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
     if (const char *e = getenv("RT_LDS_NODES")) {
       int v = atoi(e);
       if (v >= 0 && v < K.n_lds_nodes) K.n_lds_nodes = v;
     }
-    smem = K.n_lds_nodes * 208 + 16 * per_wave;
+    smem = K.n_lds_nodes * 208 + waves_per_block * per_wave;
   }
+
   // ---- schedule feedback (phase-scheduled kernels only): visit expensive tiles first ----
   K.order = nullptr;
   K.tile_cost = nullptr;

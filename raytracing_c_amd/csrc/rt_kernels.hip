@@ -815,8 +815,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
 #define PH_HIT  4     // traversal finished with a hit: wants shading
 #define PH_MISS 5     // traversal finished without a hit: wants the environment
 
-template <int WAVES, bool LDSN, bool STATS>
-__global__ __launch_bounds__(WAVES * 64) void rt_path_kernel_sched(RT_KParams P) {
+template <int WAVES, bool LDSN, bool STATS, int MIN_WAVES_PER_SIMD = 1>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel_sched(RT_KParams P) {
   // dynamic LDS: [ top of the BVH, n_lds_nodes x 13 float4 (LDSN only) ][ per wave: perm stack, depth x 64 u32 |
   //               accumulator tile, 64 pixels x 3 x u64 ]
   extern __shared__ float4 smem[];
@@ -1402,30 +1402,33 @@ __global__ void rt_test_texture_kernel(RT_KParams P, int tex, int n, const float
 // launchers (called from rt_api.cpp)
 
 // variant 1: plain while-while kernel; 2: phase-scheduled, 256-thread workgroups, nodes from L1/L2;
-// 3: phase-scheduled, one 1024-thread workgroup per CU with the top of the BVH in LDS.
-// n_waves = total wavefronts wanted; smem_bytes = dynamic LDS per workgroup (variants 2, 3).
-extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
-  if (variant == 1) {
-    hipLaunchKernelGGL(rt_path_kernel, dim3((n_waves + 3) / 4), dim3(RT_BLOCK_THREADS), 0, stream, *P);
-  } else if (variant == 2) {
-    hipLaunchKernelGGL((rt_path_kernel_sched<4, false, false>), dim3((n_waves + 3) / 4), dim3(256), smem_bytes, stream, *P);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<16, true, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<16, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-    if (variant == 4)    // diagnostic build: same kernel plus block-execution statistics in counters[8..23]
-      hipLaunchKernelGGL((rt_path_kernel_sched<16, true, true>), dim3((n_waves + 15) / 16), dim3(1024), smem_bytes, stream, *P);
-    else
-      hipLaunchKernelGGL((rt_path_kernel_sched<16, true, false>), dim3((n_waves + 15) / 16), dim3(1024), smem_bytes, stream, *P);
+// 3: phase-scheduled, one 1024-thread workgroup per CU with the top of the BVH in LDS (default);
+// 4: variant 3 plus block statistics (diagnostic).  (Occupancy experiments -- 5 or 6 waves per SIMD with register
+// spills and no LDS node copy, two half-size LDS copies per CU -- lost to variant 3: numbers in DESIGN.md.)
+// n_waves = total wavefronts wanted; smem_bytes = dynamic LDS per workgroup (variants >= 2).
+template <int WAVES, bool LDSN, bool STATS, int MINW>
+static int launch_sched(const RT_KParams *P, int n_waves, int smem_bytes, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set && smem_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<WAVES, LDSN, STATS, MINW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
   }
+  hipLaunchKernelGGL((rt_path_kernel_sched<WAVES, LDSN, STATS, MINW>), dim3((n_waves + WAVES - 1) / WAVES), dim3(WAVES * 64),
+                     smem_bytes, stream, *P);
   return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
+  switch (variant) {
+  case 1:
+    hipLaunchKernelGGL(rt_path_kernel, dim3((n_waves + 3) / 4), dim3(RT_BLOCK_THREADS), 0, stream, *P);
+    return (int)hipGetLastError();
+  case 2: return launch_sched<4, false, false, 1>(P, n_waves, smem_bytes, stream);
+  case 4: return launch_sched<16, true, true, 1>(P, n_waves, smem_bytes, stream);
+  default: return launch_sched<16, true, false, 1>(P, n_waves, smem_bytes, stream);
+  }
 }
 
 extern "C" int rt_launch_resolve(int width, int height, int samples, int chunks_x, int rank, int world,

@@ -65,6 +65,14 @@ def main():
                 print(f"pop_iters {pi:3d} thresh {th}: {run(16, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_POP_ITERS")
         os.environ.pop("RT_SCHED_THRESH")
+    if "occ" in knobs:
+        for kv, wpc in ((3, 16), (2, 16)):
+            os.environ["RT_KERNEL"] = str(kv)
+            os.environ["RT_WAVES_PER_CU"] = str(wpc)
+            for rep in range(2):
+                print(f"kernel {kv} waves/CU {wpc}: {run(0, 4):8.3f} ms", flush=True)
+        os.environ.pop("RT_KERNEL")
+        os.environ.pop("RT_WAVES_PER_CU")
     if "map" in knobs:
         for sm in (0, 1):
             os.environ["RT_SAMPLE_MAJOR"] = str(sm)
