@@ -9,7 +9,8 @@ import os
 from . import ctypes_abi as abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_LIB_PATH: A/B a differently built librt_hip.so (tools/exp_ab.sh); the default is the in-tree build.
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "librt_hip.so")
 
 
 class NativeLibraryMissing(RuntimeError):

@@ -15,7 +15,7 @@ from raytracing_c_amd.configs import load_config       # noqa: E402
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "helmet"
-    reps = 3
+    reps = 6
     assert rt.lib.rt_init(0) == 0
     hs, cfg = load_config(name)
     w, h, s, b = cfg["width"], cfg["height"], cfg["samples"], cfg["max_bounces"]
@@ -65,12 +65,15 @@ def main():
                 print(f"pop_iters {pi:3d} thresh {th}: {run(16, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_POP_ITERS")
         os.environ.pop("RT_SCHED_THRESH")
+    if "slab16" in knobs:
+        for slab in (8, 16):
+            print(f"slab {slab:2d}: {run(slab, 4):8.3f} ms", flush=True)
     if "occ" in knobs:
-        for kv, wpc in ((3, 16), (2, 16)):
+        for kv, wpc in ((3, 16), (5, 16), (3, 16), (5, 16)):
             os.environ["RT_KERNEL"] = str(kv)
             os.environ["RT_WAVES_PER_CU"] = str(wpc)
-            for rep in range(2):
-                print(f"kernel {kv} waves/CU {wpc}: {run(0, 4):8.3f} ms", flush=True)
+            for slab in (4, 8, 16, 32):
+                print(f"kernel {kv} slab {slab:2d}: {run(slab, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_KERNEL")
         os.environ.pop("RT_WAVES_PER_CU")
     if "map" in knobs:
