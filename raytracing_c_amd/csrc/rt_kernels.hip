@@ -1016,7 +1016,15 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
           }
           dirty &= ~(1u << level);
-          phase = PH_POP;
+          // the nearest child is taken right here, on the dense set of lanes of this block (its distance was
+          // just compared with hit.t); only a node without candidates sends the lane to the pop loop
+          if (cur >> 24) {
+            child = 8 * node + 1 + (int)(cur & 7u);
+            cur = ((cur >> 3) & 0x1FFFFFu) | (((cur >> 24) - 1u) << 24);
+            phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
+          } else {
+            phase = PH_POP;
+          }
         }
       }
 
@@ -1040,8 +1048,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
               node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
               level = target;
               cur = perm[level * 64 + lane];
+              cnt = cur >> 24;                  // > 0: the level is marked live
             }
-          } else {
+          }
+          if (phase == PH_POP) {                // same round: take the next child of the (possibly new) level
             int j = (int)(cur & 7u);
             cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
             bool go = true;
