@@ -157,6 +157,16 @@ extern void scene_init(Scene *scene, Triangle_Slice src_triangles, Allocator all
 /* Releases what scene_init allocated with the default allocator. */
 extern void rt_scene_free(Scene *scene);
 
+/* The `.scene` cache file, reference scene.h:99-100 / scene.c:13-76: a 96-byte header
+ * {i32 version, n_nodes, n_triangles, bvh_depth; Camera}, the BVH nodes, then the triangle allocation (nine f32
+ * arrays + Triangle_AOS records), all raw.  scene_load_bytes has the reference's signature and semantics: the
+ * scene ALIASES `data` (32-byte aligned, kept alive by the caller); false on a short / inconsistent file.
+ * scene_save_bytes replaces scene_save_writer (the codin `Writer` is not part of the reference tree): it writes
+ * the same bytes into a caller buffer of scene_file_size() bytes and returns the count, or -1 when too small. */
+extern bool  scene_load_bytes(Byte_Slice data, Scene *scene);
+extern isize scene_save_bytes(Scene const *scene, byte *dst, isize capacity);
+extern isize scene_file_size(Scene const *scene);
+
 #ifdef __cplusplus
 }
 #endif

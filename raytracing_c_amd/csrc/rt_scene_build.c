@@ -265,3 +265,74 @@ void rt_scene_free(Scene *scene) {
   scene->bvh.nodes.len  = 0;
   memset(&scene->triangles, 0, sizeof scene->triangles);
 }
+
+/* ---- the `.scene` cache file, reference scene.c:13-76 ---------------------------------------------
+ * Byte layout (little endian, the reference writes its structs raw):
+ *   header  { i32 version = 0, n_nodes, n_triangles, bvh_depth; Camera camera; } padded to 32-byte alignment (96 B)
+ *   nodes   n_nodes x BVH_Node (192 B)
+ *   tris    9 x n_triangles f32 (x[0..2], y[0..2], z[0..2]) then n_triangles x Triangle_AOS (112 B)
+ * The Shader pointers inside Triangle_AOS are the writer's host addresses, as in the reference: a loaded scene
+ * is good for traversal and for the BVH visualiser, and needs its shaders re-bound before it is rendered. */
+typedef struct __attribute__((aligned(32))) {
+  i32    version, n_nodes, n_triangles, bvh_depth;
+  Camera camera;
+} Scene_File_Header;
+
+isize scene_file_size(Scene const *scene) {
+  return (isize)sizeof(Scene_File_Header) + scene->bvh.nodes.len * (isize)sizeof(BVH_Node) +
+         TRIANGLES_ALLOCATION_SIZE(scene->triangles.len);
+}
+
+/* scene.c:18-34 with the codin Writer replaced by a caller buffer: returns the bytes written, or -1 when
+ * `capacity` is too small (nothing is written then). */
+isize scene_save_bytes(Scene const *scene, byte *dst, isize capacity) {
+  isize total = scene_file_size(scene);
+  if (!dst || capacity < total) return -1;
+  Scene_File_Header header;
+  memset(&header, 0, sizeof header);
+  header.version     = 0;
+  header.n_nodes     = (i32)scene->bvh.nodes.len;
+  header.n_triangles = scene->triangles.len;
+  header.bvh_depth   = (i32)scene->bvh.depth;
+  header.camera      = scene->camera;
+  memcpy(dst, &header, sizeof header);
+  dst += sizeof header;
+  isize node_bytes = scene->bvh.nodes.len * (isize)sizeof(BVH_Node);
+  if (node_bytes > 0) memcpy(dst, scene->bvh.nodes.data, (size_t)node_bytes);
+  dst += node_bytes;
+  isize tri_bytes = TRIANGLES_ALLOCATION_SIZE(scene->triangles.len);
+  if (tri_bytes > 0) memcpy(dst, scene->triangles.x[0], (size_t)tri_bytes);
+  return total;
+}
+
+/* scene.c:36-76.  The scene ALIASES `data` (no copy), so `data` must stay alive and be 32-byte aligned; returns
+ * false on a short or inconsistent file (the reference asserts on misalignment, this returns false).  Sets
+ * last_row_offset, which the reference's loader leaves unset (scene.c:420 sets it only in scene_init). */
+bool scene_load_bytes(Byte_Slice data, Scene *scene) {
+  Scene_File_Header header;
+  if (!data.data || !scene || ((uintptr_t)data.data % 32) != 0) return false;
+  if (data.len < (isize)sizeof header) return false;
+  memcpy(&header, data.data, sizeof header);
+  if (header.version != 0 || header.n_nodes < 0 || header.n_triangles < 0 || header.bvh_depth < 0) return false;
+  if (data.len != (isize)sizeof header + (isize)header.n_nodes * (isize)sizeof(BVH_Node) +
+                      TRIANGLES_ALLOCATION_SIZE(header.n_triangles))
+    return false;
+  if (header.bvh_depth > 10 || header.n_nodes != bvh_n_internal_nodes(header.bvh_depth)) return false;
+  if ((header.n_triangles % RT_BVH_WIDTH) != 0) return false;
+
+  scene->camera               = header.camera;
+  scene->bvh.depth            = header.bvh_depth;
+  scene->bvh.last_row_offset  = header.n_nodes;
+  scene->bvh.nodes.len        = header.n_nodes;
+  scene->bvh.nodes.data       = (BVH_Node *)(data.data + sizeof header);
+  f32 *tris = (f32 *)(data.data + sizeof header + (size_t)header.n_nodes * sizeof(BVH_Node));
+  isize n = header.n_triangles;
+  for (int k = 0; k < 3; k++) {
+    scene->triangles.x[k] = tris + n * (0 + k);
+    scene->triangles.y[k] = tris + n * (3 + k);
+    scene->triangles.z[k] = tris + n * (6 + k);
+  }
+  scene->triangles.aos = (Triangle_AOS *)(tris + n * 9);
+  scene->triangles.len = header.n_triangles;
+  return true;
+}

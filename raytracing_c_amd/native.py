@@ -83,6 +83,12 @@ def _declare(d):
     d.scene_init.restype = None
     d.rt_scene_free.argtypes = [P(abi.Scene)]
     d.rt_scene_free.restype = None
+    d.scene_load_bytes.argtypes = [abi.Byte_Slice, P(abi.Scene)]
+    d.scene_load_bytes.restype = C.c_bool
+    d.scene_save_bytes.argtypes = [P(abi.Scene), vp, C.c_ssize_t]
+    d.scene_save_bytes.restype = C.c_ssize_t
+    d.scene_file_size.argtypes = [P(abi.Scene)]
+    d.scene_file_size.restype = C.c_ssize_t
     d.rt_scene_upload.argtypes = [P(abi.Scene)]
     d.rt_scene_upload.restype = vp
     d.rt_scene_release.argtypes = [vp]
