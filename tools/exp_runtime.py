@@ -68,14 +68,11 @@ def main():
     if "slab16" in knobs:
         for slab in (8, 16):
             print(f"slab {slab:2d}: {run(slab, 4):8.3f} ms", flush=True)
-    if "occ" in knobs:
-        for kv, wpc in ((3, 16), (5, 16), (3, 16), (5, 16)):
-            os.environ["RT_KERNEL"] = str(kv)
-            os.environ["RT_WAVES_PER_CU"] = str(wpc)
-            for slab in (4, 8, 16, 32):
-                print(f"kernel {kv} slab {slab:2d}: {run(slab, 4):8.3f} ms", flush=True)
-        os.environ.pop("RT_KERNEL")
-        os.environ.pop("RT_WAVES_PER_CU")
+    if "ldsn" in knobs:     # how many leading BVH nodes need to be in LDS
+        for nl in (0, 9, 73, 105, 150, 200, 290, 100000):
+            os.environ["RT_LDS_NODES"] = str(nl)
+            print(f"lds nodes {nl:6d}: {run(16, 4):8.3f} ms", flush=True)
+        os.environ.pop("RT_LDS_NODES")
     if "map" in knobs:
         for sm in (0, 1):
             os.environ["RT_SAMPLE_MAJOR"] = str(sm)
