@@ -478,12 +478,17 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   K->sample_first = p->sample_first;
   K->sample_end = p->sample_count > 0 ? p->sample_first + p->sample_count : p->samples;
   int n_samples = K->sample_end - K->sample_first;
-  // samples per work item: 16, or 8 when that would leave fewer than 32 items per wave (a rank of an 8-GPU
-  // partition, or a low-spp frame): measured on 1/8 of the helmet frame 8.3 ms against 8.7 (16) and 9.7 (4)
+  // samples per work item: the largest of 32 / 16 / 8 that still leaves 24 items per wave (16 waves per CU).  Big
+  // items keep a wave on few pixels and have fewer end-of-item bubbles, small ones balance the end of the launch;
+  // measured on the helmet frame (ms): whole frame 53.3 (16) 52.0 (32) 52.8 (64); 1/2 frame 27.0 (16) 26.7 (32)
+  // 30.1 (64); 1/4 frame 16.0 (8) 15.7 (16) 16.1 (32); 1/8 frame 8.1 (4) 6.9 (8) 7.0 (16) 7.8 (32).
   int slab = p->slab;
   if (slab <= 0) {
-    int64_t items16 = (int64_t)K->n_local_chunks * 16 * ((n_samples + 15) / 16);
-    slab = (items16 < (int64_t)32 * g_num_cus * 16) ? 8 : 16;
+    slab = 8;
+    for (int cand = 32; cand > 8; cand >>= 1) {
+      int64_t items = (int64_t)K->n_local_chunks * 16 * ((n_samples + cand - 1) / cand);
+      if (items >= (int64_t)24 * g_num_cus * 16) { slab = cand; break; }
+    }
   }
   int shift = 0;
   while ((1 << shift) < slab && (1 << shift) < n_samples) shift++;

@@ -89,9 +89,13 @@ def test_loaded_scene_renders_like_the_original():
     ok, ld = _load(buf)
     assert ok
     ld.background = hs.scene.background                              # not part of the file (scene.c:18-34)
-    loaded = type(hs).__new__(type(hs))
+    loaded = type(hs).__new__(type(hs))                             # a view: owns nothing, never frees
     loaded.__dict__.update(hs.__dict__)
     loaded.scene = ld
-    out = render_frame(loaded, 96, 64, 4, 4, seed=0x1234ABCD)
+    loaded._freed = True
+    try:
+        out = render_frame(loaded, 96, 64, 4, 4, seed=0x1234ABCD)
+    finally:
+        rt.lib.rt_scene_invalidate(C.byref(ld))                      # drop the device copy cached for this Scene*
     assert np.array_equal(out["image"], ref["image"])
     assert out["counters"].rays == ref["counters"].rays

@@ -31,6 +31,14 @@ def run(s, rank=0, world=1, slab=0, reps=5):
 
 
 run(256)
+if os.environ.get("RT_EXP") == "slab":      # best slab per partition size
+    for world in (1, 2, 4, 8):
+        for slab in (4, 8, 16, 32, 64):
+            if world == 1 and slab < 16 or world >= 4 and slab > 32:
+                continue
+            ms, rays = run(256, world // 2, world, slab)
+            print(f"world {world} rank {world // 2} slab {slab:3d}: {ms:8.3f} ms", flush=True)
+    sys.exit(0)
 for s in (256, 128, 64, 32, 16, 8):
     ms, rays = run(s)
     print(f"samples {s:4d} world 1: {ms:8.3f} ms  {rays/ms/1e3:8.1f} Mray/s", flush=True)

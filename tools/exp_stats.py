@@ -22,11 +22,12 @@ hs, cfg = load_config(name)
 w, h, s, b = cfg["width"], cfg["height"], cfg["samples"], cfg["max_bounces"]
 d = rt.lib.rt_scene_upload(C.byref(hs.scene))
 accum = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda")
-for env in ({}, {"RT_SCHED_THRESH": "32"}, {"RT_SCHED_THRESH": "56"}):
+SLAB = int(os.environ.get("RT_EXP_SLAB", "0"))
+for env in ({},) if SLAB else ({}, {"RT_SCHED_THRESH": "32"}, {"RT_SCHED_THRESH": "56"}):
     for k, v in env.items():
         os.environ[k] = v
-    os.environ["RT_KERNEL"] = "4"
-    p = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, 0, 1, 0, 0)
+    os.environ["RT_KERNEL"] = os.environ.get("RT_EXP_KERNEL", "4")
+    p = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, 0, 1, SLAB, 0)
     accum.zero_()
     assert rt.lib.rt_render_accumulate(d, C.byref(p), accum.data_ptr(), None) == 0, rt.last_error()
     torch.cuda.synchronize()
