@@ -1,0 +1,99 @@
+"""Edge cases of the render entry points (GPU): empty scene, tiny and ragged frames, one sample / one bounce, an image with
+row padding and an alpha channel, a second frame on the same context."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracing_c_amd as rt
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    return rt
+
+
+def _empty_scene():
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.scene import Material, build_scene
+    cam = np.eye(4, dtype=np.float32)
+    z = np.zeros((0, 3, 3), np.float32)
+    return build_scene(z, z, np.zeros((0, 3, 2), np.float32), np.zeros((0,), np.int32), [Material()], [], cam, 1.0,
+                       procedural_background(64, 32))
+
+
+def test_empty_scene_is_all_background(rt, oracle):
+    """0 triangles: depth 0, one all-zero leaf group; every path is one ray into the environment."""
+    from tests import _oracle
+    hs = _empty_scene()
+    assert hs.scene.bvh.depth == 0 and hs.scene.triangles.len == 8
+    want = _oracle.render(hs, 40, 24, 3, 4)
+    got = rt.render_frame(hs, 40, 24, 3, 4, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    c = got["counters"]
+    assert c.paths == 40 * 24 * 3 and c.rays == c.paths and c.backgrounds == c.paths and c.shades == 0
+
+
+@pytest.mark.parametrize("w,h,s,b", [(1, 1, 1, 1), (1, 1, 5, 8), (3, 2, 2, 1), (33, 1, 4, 4), (1, 33, 4, 4), (8, 8, 1, 8),
+                                     (65, 31, 1, 1)])
+def test_tiny_and_ragged_frames(rt, oracle, w, h, s, b):
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("spheres")
+    want = _oracle.render(hs, w, h, s, b)
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    assert got["counters"].paths == w * h * s
+    assert got["counters"].rays == want["counters"]["rays"]
+
+
+def test_image_with_row_padding_and_alpha(rt, oracle):
+    """Image.stride > width and components = 4 (driver.c:747-754 allocates RGB; codin images may carry more):
+    pixel (x, y) component c lives at pixels[(x + y * stride) * components + c]; everything else stays untouched."""
+    from raytracing_c_amd import ctypes_abi as abi
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("spheres")
+    w, h, stride, comp = 37, 21, 48, 4
+    want = _oracle.render(hs, w, h, 4, 4)["image"]
+    buf = np.full((h, stride, comp), 0xAB, np.uint8)
+    ctx = abi.Rendering_Context()
+    ctx.image.components = comp
+    ctx.image.pixel_type = 0
+    ctx.image.width = w
+    ctx.image.stride = stride
+    ctx.image.height = h
+    ctx.image.pixels.data = buf.ctypes.data
+    ctx.image.pixels.len = buf.size
+    ctx.scene = C.pointer(hs.scene)
+    ctx.samples = 4
+    ctx.max_bounces = 4
+    ctx.n_threads = 1
+    ctx._current_chunk = 0
+    rt.lib.rt_set_seed(0x1234ABCD)
+    rt.lib.rt_clear_error()
+    rt.lib.render_thread_proc(C.byref(ctx))
+    assert rt.last_error() == ""
+    assert rt.lib.rendering_context_is_finished(C.byref(ctx))
+    assert np.array_equal(buf[:, :w, :3], want)
+    assert np.all(buf[:, :w, 3] == 0xAB), "alpha channel must not be written"
+    assert np.all(buf[:, w:, :] == 0xAB), "row padding must not be written"
+
+
+def test_second_frame_on_the_same_scene_reuses_the_device_copy(rt, oracle):
+    """Two Rendering_Contexts on one Scene* (what an animation loop does): same device scene, new camera honoured."""
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, cfg = load_config("spheres")
+    a = rt.render_context(hs, 64, 40, 2, 4)["image"]
+    m = np.ctypeslib.as_array(hs.scene.camera.view_matrix.rows).reshape(4, 4).copy()
+    m[0, 3] += 0.75                                                       # move the camera: the Scene pointer stays the same
+    hs.set_camera(m, float(hs.scene.camera.fov))
+    want = _oracle.render(hs, 64, 40, 2, 4)["image"]
+    b = rt.render_context(hs, 64, 40, 2, 4)["image"]
+    assert np.array_equal(b, want)
+    assert not np.array_equal(a, b)
