@@ -6,6 +6,7 @@ one Triangle per face with shader = {&material, disney_shader_proc}, background 
 looked up by sample_background.
 """
 import ctypes as C
+import time
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -71,6 +72,7 @@ class HostScene:
         self.n_input_triangles = 0
         self.shader_kind = "disney"
         self._freed = False
+        self.scene_init_seconds = 0.0
 
     # --- convenience views -------------------------------------------------------------
     @property
@@ -188,7 +190,9 @@ def build_scene(positions, normals, uvs, material_ids, materials: List[Material]
     set_camera(hs.scene.camera, camera_matrix, yfov)
 
     sl = abi.Triangle_Slice(tri.ctypes.data, n)
+    t0 = time.perf_counter()
     lib.scene_init(C.byref(hs.scene), sl, abi.Allocator(None, None))
+    hs.scene_init_seconds = time.perf_counter() - t0
     if not hs.scene.triangles.x[0]:
         raise MemoryError("scene_init failed")
     return hs

@@ -72,7 +72,7 @@ def test_denoiser_removes_a_firefly(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(64, 64, 3), (45, 71, 3), (33, 31, 4), (1, 1, 3), (2, 130, 3)])
+@pytest.mark.parametrize("shape", [(64, 64, 3), (45, 71, 3), (33, 31, 4), (1, 1, 3), (2, 130, 3), (40, 100, 3), (21, 96, 3)])
 def test_gpu_denoiser_bit_exact(oracle, shape):
     import raytracing_c_amd as rt
     assert rt.lib.rt_init(0) == 0, rt.last_error()
