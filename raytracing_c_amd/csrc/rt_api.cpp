@@ -193,33 +193,62 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes) {
   return 0;
 }
 
-static int texture_index(Image const *img, std::unordered_map<const Image *, int> &map, std::vector<RT_DTexture> &descs,
-                         std::vector<uint32_t> &texels) {
+// Textures are packed to RGBA8 words ON THE GPU: the host only records which Images are used (in first-use order)
+// and where each one starts in the texel pool; upload_textures() copies the raw rows and runs rt_pack_texture_kernel.
+struct TexturePool {
+  std::unordered_map<const Image *, int> map;
+  std::vector<RT_DTexture>               descs;
+  std::vector<const Image *>             sources;
+  size_t                                 texels = 0;
+};
+
+static int texture_index(Image const *img, TexturePool &pool) {
   if (!img) return -1;
-  auto it = map.find(img);
-  if (it != map.end()) return it->second;
+  auto it = pool.map.find(img);
+  if (it != pool.map.end()) return it->second;
   if (img->components < 3 || img->width <= 0 || img->height <= 0 || !img->pixels.data || img->stride < img->width) {
     return -2;
   }
   RT_DTexture t;
-  t.offset = (uint32_t)texels.size();
+  t.offset = (uint32_t)pool.texels;
   t.width = (int32_t)img->width;
   t.height = (int32_t)img->height;
   t.stride = (int32_t)img->width;
-  size_t base = texels.size();
-  texels.resize(base + (size_t)img->width * img->height);
-  for (isize y = 0; y < img->height; y++) {
-    const byte *row = img->pixels.data + img->components * (img->stride * y);
-    uint32_t   *dst = texels.data() + base + (size_t)y * img->width;
-    for (isize x = 0; x < img->width; x++) {
-      const byte *p = row + img->components * x;
-      dst[x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
-    }
-  }
-  int idx = (int)descs.size();
-  descs.push_back(t);
-  map[img] = idx;
+  pool.texels += (size_t)img->width * img->height;
+  int idx = (int)pool.descs.size();
+  pool.descs.push_back(t);
+  pool.sources.push_back(img);
+  pool.map[img] = idx;
   return idx;
+}
+
+extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
+                                      hipStream_t stream);
+
+static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t *bytes) {
+  size_t n = pool.texels ? pool.texels * 4 : 16;
+  HIP_TRY(hipMalloc((void **)d_texels, n));
+  *bytes += (int64_t)n;
+  size_t max_raw = 0;
+  for (const Image *img : pool.sources) {
+    size_t raw = (size_t)img->stride * img->height * img->components;
+    if (raw > max_raw) max_raw = raw;
+  }
+  if (max_raw == 0) return 0;
+  uint8_t *stage = nullptr;
+  HIP_TRY(hipMalloc((void **)&stage, max_raw));
+  int rc = 0;
+  for (size_t k = 0; k < pool.sources.size() && rc == 0; k++) {
+    const Image *img = pool.sources[k];
+    size_t raw = (size_t)img->stride * img->height * img->components;
+    rc = (int)hipMemcpy(stage, img->pixels.data, raw, hipMemcpyHostToDevice);
+    if (rc == 0) rc = rt_launch_pack_texture(stage, (int)img->width, (int)img->height, (int)img->stride, (int)img->components,
+                                             *d_texels + pool.descs[k].offset, nullptr);
+    if (rc == 0) rc = (int)hipDeviceSynchronize();        // the staging buffer is reused by the next texture
+  }
+  (void)hipFree(stage);
+  if (rc != 0) return rt_fail("texture upload failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
 }
 
 static float int_bits(int32_t i) {
@@ -256,9 +285,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
     return nullptr;
   }
 
-  std::unordered_map<const Image *, int> tex_map;
-  std::vector<RT_DTexture>               descs;
-  std::vector<uint32_t>                  texels;
+  TexturePool pool;
   std::unordered_map<uint64_t, int>      mat_map;     // (data ptr, kind) -> id
   std::vector<float>                     mats;
 
@@ -286,10 +313,10 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
         mat = it->second;
       } else {
         const PBR_Shader_Data *d = (const PBR_Shader_Data *)a.shader.data;
-        int ta = texture_index(d->texture_albedo, tex_map, descs, texels);
-        int tn = texture_index(d->texture_normal, tex_map, descs, texels);
-        int tm = texture_index(d->texture_metal_roughness, tex_map, descs, texels);
-        int te = texture_index(d->texture_emission, tex_map, descs, texels);
+        int ta = texture_index(d->texture_albedo, pool);
+        int tn = texture_index(d->texture_normal, pool);
+        int tm = texture_index(d->texture_metal_roughness, pool);
+        int te = texture_index(d->texture_emission, pool);
         if (ta == -2 || tn == -2 || tm == -2 || te == -2) {
           rt_fail("rt_scene_upload: material of triangle %d references an unusable Image (need u8, >=3 components)", i);
           return nullptr;
@@ -342,13 +369,13 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
     nodes.assign(src, src + (size_t)scene->bvh.nodes.len * 48);
   }
 
-  int bg = texture_index((Image const *)scene->background.data, tex_map, descs, texels);
+  int bg = texture_index((Image const *)scene->background.data, pool);
   if (bg < 0) { rt_fail("rt_scene_upload: background Image is unusable (need u8, >=3 components)"); return nullptr; }
 
   RT_Device_Scene *d = new RT_Device_Scene();
   if (upload(&d->nodes, nodes, &d->bytes) || upload(&d->leaves, leaves, &d->bytes) ||
       upload(&d->tris, tris, &d->bytes) || upload(&d->mats, mats, &d->bytes) ||
-      upload(&d->textures, descs, &d->bytes) || upload(&d->texels, texels, &d->bytes)) {
+      upload(&d->textures, pool.descs, &d->bytes) || upload_textures(pool, &d->texels, &d->bytes)) {
     free_device_scene(d);
     return nullptr;
   }
@@ -358,7 +385,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   d->n_nodes = (int32_t)scene->bvh.nodes.len;
   d->n_triangles = n;
   d->n_materials = (int32_t)(mats.size() / 20);
-  d->n_textures = (int32_t)descs.size();
+  d->n_textures = (int32_t)pool.descs.size();
   d->fp_nodes = scene->bvh.nodes.data;
   d->fp_tris = T.x[0];
   d->fp_bg = scene->background.data;

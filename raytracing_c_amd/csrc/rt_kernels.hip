@@ -1459,6 +1459,23 @@ extern "C" int rt_launch_untile(int width, int height, int chunks_x, int n_chunk
   return (int)hipGetLastError();
 }
 
+// raw u8 image rows (stride pixels x comp bytes, comp >= 3) -> RGBA8 words, row-major width x height
+__global__ void rt_pack_texture_kernel(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)width * height) return;
+  int y = (int)(i / width), x = (int)(i % width);
+  const uint8_t *p = raw + ((size_t)y * stride + x) * comp;
+  out[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
+}
+
+extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
+                                      hipStream_t stream) {
+  size_t n = (size_t)width * height;
+  hipLaunchKernelGGL(rt_pack_texture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, width, height, stride,
+                     comp, out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream) {
   hipLaunchKernelGGL(rt_test_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, n, x, y, out);
   return (int)hipGetLastError();
