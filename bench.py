@@ -97,7 +97,12 @@ def cpu_baseline(hs, cfg, target_seconds):
     r = _oracle.render(hs, w, h, spp, b, n_threads=cores, lib=lib)
     dt = time.perf_counter() - t0
     rays = r["counters"]["rays"]
+    # per-core figure (SURVEY.md section 8d asks for T = all threads and T = 1): 2 spp of the same frame on one thread
+    t0 = time.perf_counter()
+    r1 = _oracle.render(hs, w, h, 2, b, n_threads=1, lib=lib)
+    dt1 = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "single_thread_mray_per_s": r1["counters"]["rays"] / dt1 / 1e6,
             "sample": f"{cfg['asset']} {w}x{h}, {spp} of {cfg['samples']} spp, {b} bounces, {dt:.1f} s, "
                       f"oracle -O3 -march=native, {cores} threads",
             "msample_per_s": w * h * spp / dt / 1e6}
