@@ -272,7 +272,7 @@ def main():
             "config": {"workload": workload,
                        "scene": "assets/helmet.glb = self-contained models/helmet.gltf; procedural 2048x1024 "
                                 "equirect background (background.png is a missing blob); seed 0x1234ABCD",
-                       "partition": f"32x32 chunks interleaved over {world} GPU(s), {'RCCL' if backend == 'nccl' else backend} "
+                       "partition": f"32x32 chunks dealt to {world} GPU(s) by the (cx + B cy) mod world lattice, {'RCCL' if backend == 'nccl' else backend} "
                                     "all-gather of u8 tiles" if world > 1 else "single GPU"},
             "fps": 1.0 / sec_per_step,
             "msample_per_s": w * h * s / sec_per_step / 1e6,

@@ -68,7 +68,7 @@ typedef struct {
   i32 samples;           /* samples per pixel (Rendering_Context.samples)       */
   i32 max_bounces;       /* Rendering_Context.max_bounces                       */
   u32 seed;              /* frame seed                                          */
-  i32 rank, world;       /* this process renders chunk c iff c % world == rank  */
+  i32 rank, world;       /* this process renders the chunks rt_chunk_owner() gives `rank` */
   i32 slab;              /* samples per work item (0 = library default)         */
   i32 flags;             /* RT_FLAG_*                                           */
   i32 sample_first;      /* this call traces samples [sample_first,             */
@@ -82,10 +82,21 @@ enum {
   RT_FLAG_NONE = 0,
 };
 
-/* Number of 32x32 chunks of a width x height image, and how many of them
- * `rank` owns under the interleaved partition. */
+/* Image partition across the GPUs of a node.  The frame is cut into the reference's 32x32 chunks
+ * (raytracer.c:601-610; chunk c = cx + cy * ceil(width / 32)); chunk (cx, cy) belongs to rank
+ * (cx + B * cy) mod world, B = the integer coprime to `world` nearest to 0.618 * world, so that every
+ * chunk column and row is spread over all ranks.  A rank numbers its chunks in ascending global order.
+ * Pure host arithmetic (no GPU needed):
+ *   rt_chunk_count           chunks of the image
+ *   rt_chunk_owner           rank that owns `chunk`, -1 if out of range
+ *   rt_local_chunk_count     chunks `rank` owns
+ *   rt_max_local_chunk_count the largest of those over all ranks (= slots per rank in the gathered tile buffer)
+ *   rt_local_chunk_list      writes up to `capacity` of rank's chunk indices to out, returns the count */
 extern i32 rt_chunk_count(i32 width, i32 height);
+extern i32 rt_chunk_owner(i32 width, i32 height, i32 world, i32 chunk);
 extern i32 rt_local_chunk_count(i32 width, i32 height, i32 rank, i32 world);
+extern i32 rt_max_local_chunk_count(i32 width, i32 height, i32 world);
+extern i32 rt_local_chunk_list(i32 width, i32 height, i32 rank, i32 world, i32 *out, i32 capacity);
 
 /* Renders this rank's chunks.  All pointers are DEVICE pointers owned by the
  * caller, `stream` is a hipStream_t (NULL = default stream); the call only
@@ -105,7 +116,7 @@ extern int rt_resolve(RT_Render_Params const *params, void const *d_accum,
                       void *d_tiles, void *d_image, void *d_linear, void *stream);
 
 /* Scatters gathered compact tiles of ALL ranks (rank-major:
- * [world][max_local_chunks][32*32*3]) into a row-major u8 image on the device. */
+ * [world][rt_max_local_chunk_count()][32*32*3]) into a row-major u8 image on the device. */
 extern int rt_untile(i32 width, i32 height, i32 world, void const *d_all_tiles,
                      void *d_image, void *stream);
 

@@ -90,6 +90,7 @@ typedef struct {
   unsigned long long *accum;   /* [height*width*3] 32.32 fixed point      */
   unsigned long long *counters;/* RT_N_COUNTERS                           */
   uint32_t *work_head;         /* dequeue counter                         */
+  const int32_t *local_chunks; /* global chunk index of this rank's l-th chunk (partition table) */
   const uint32_t *order;       /* tile visiting order (NULL = identity)   */
   uint32_t *tile_cost;         /* rays per tile of THIS launch (NULL = off)*/
   unsigned long long *wave_times; /* diagnostic kernel: per wave start, end (100 MHz), items */

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
     const int slab_idx = (int)(w % (uint32_t)P.n_slabs);
     const int tile_idx = (int)(w / (uint32_t)P.n_slabs);
     const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
-    const int chunk = lchunk * P.world + P.rank;
+    const int chunk = P.local_chunks[lchunk];
     const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
     const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
     if (tile_x0 >= P.width || tile_y0 >= P.height) continue;   // tile entirely outside
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     const int tile_pos = (int)(w / (uint32_t)P.n_slabs);
     const int tile_idx = P.order ? (int)P.order[tile_pos] : tile_pos;
     const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
-    const int chunk = lchunk * P.world + P.rank;
+    const int chunk = P.local_chunks[lchunk];
     const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
     const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
     if (tile_x0 >= P.width || tile_y0 >= P.height) continue;
@@ -1118,13 +1118,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // ---------------------------------------------------------------------------------
 // accum -> mean -> clamp -> sRGB -> u8 (raytracer.c:700-716), one thread per pixel
 // of this rank's chunks.
-__global__ void rt_resolve_kernel(int width, int height, int samples, int chunks_x, int rank, int world,
+__global__ void rt_resolve_kernel(int width, int height, int samples, int chunks_x, const int32_t *local_chunks,
                                   int n_local_chunks, const unsigned long long *accum,
                                   uint8_t *tiles, uint8_t *image, float *linear) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_local_chunks * 1024) return;
   int lchunk = idx >> 10, p = idx & 1023;
-  int chunk = lchunk * world + rank;
+  int chunk = local_chunks[lchunk];
   int x = (chunk % chunks_x) * 32 + (p & 31);
   int y = (chunk / chunks_x) * 32 + (p >> 5);
   uint8_t rgb[3] = {0, 0, 0};
@@ -1145,8 +1145,8 @@ __global__ void rt_resolve_kernel(int width, int height, int samples, int chunks
   }
 }
 
-// gathered compact tiles [world][max_local][1024*3] -> row-major image
-__global__ void rt_untile_kernel(int width, int height, int chunks_x, int n_chunks, int world, int max_local,
+// gathered compact tiles [world][max_local][1024*3] -> row-major image; owner_slot[chunk] = rank * max_local + slot
+__global__ void rt_untile_kernel(int width, int height, int chunks_x, int n_chunks, const int32_t *owner_slot,
                                  const uint8_t *all_tiles, uint8_t *image) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_chunks * 1024) return;
@@ -1154,8 +1154,7 @@ __global__ void rt_untile_kernel(int width, int height, int chunks_x, int n_chun
   int x = (chunk % chunks_x) * 32 + (p & 31);
   int y = (chunk / chunks_x) * 32 + (p >> 5);
   if (x >= width || y >= height) return;
-  int rank = chunk % world, lchunk = chunk / world;
-  const uint8_t *src = all_tiles + (((size_t)rank * max_local + lchunk) * 1024 + p) * 3;
+  const uint8_t *src = all_tiles + ((size_t)owner_slot[chunk] * 1024 + p) * 3;
   uint8_t *dst = image + ((size_t)y * width + x) * 3;
   dst[0] = src[0];
   dst[1] = src[1];
@@ -1441,21 +1440,21 @@ extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int varia
   }
 }
 
-extern "C" int rt_launch_resolve(int width, int height, int samples, int chunks_x, int rank, int world,
+extern "C" int rt_launch_resolve(int width, int height, int samples, int chunks_x, const int32_t *local_chunks,
                                  int n_local_chunks, const unsigned long long *accum, uint8_t *tiles,
                                  uint8_t *image, float *linear, hipStream_t stream) {
   int n = n_local_chunks * 1024;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(rt_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, width, height, samples,
-                     chunks_x, rank, world, n_local_chunks, accum, tiles, image, linear);
+                     chunks_x, local_chunks, n_local_chunks, accum, tiles, image, linear);
   return (int)hipGetLastError();
 }
 
-extern "C" int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, int world, int max_local,
+extern "C" int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, const int32_t *owner_slot,
                                 const uint8_t *all_tiles, uint8_t *image, hipStream_t stream) {
   int n = n_chunks * 1024;
   hipLaunchKernelGGL(rt_untile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, width, height, chunks_x,
-                     n_chunks, world, max_local, all_tiles, image);
+                     n_chunks, owner_slot, all_tiles, image);
   return (int)hipGetLastError();
 }
 

@@ -1,7 +1,8 @@
 """Image partition across the GPUs of one node and the framebuffer tile gather.
 
-The reference work-steals 32x32 chunks between threads (raytracer.c:601-627); here chunk c is
-owned by rank c % world (interleaving balances sky-only against helmet-covered chunks), every
+The reference work-steals 32x32 chunks between threads (raytracer.c:601-627); here chunk (cx, cy) is
+owned by rank (cx + B * cy) % world (a lattice that spreads every chunk column and row over all ranks:
+include/rt_hip.h, rt_chunk_owner), every
 rank renders its chunks with rt_render_accumulate / rt_resolve into a compact
 [max_local][32*32*3] u8 tile buffer, ONE RCCL all-gather moves the tiles over xGMI (6.2 MB for
 1080p in total) and rt_untile scatters them into the row-major image.  Per-path seeds depend
@@ -10,24 +11,41 @@ only on (pixel, sample), so the image does not depend on `world`.
 extract_tiles()/untile() are numpy statements of the two layouts (what rt_resolve writes and
 what rt_untile reads); the CPU tests use them with gloo.
 """
+import ctypes as C
+
 import numpy as np
 
 CHUNK = 32
 
 
 class FramePartition:
+    """The library's partition tables (pure host arithmetic in librt_hip.so, no GPU needed)."""
+
     def __init__(self, width, height, world):
+        from .native import lib
         self.width, self.height, self.world = int(width), int(height), int(world)
         self.chunks_x = (self.width + CHUNK - 1) // CHUNK
         self.chunks_y = (self.height + CHUNK - 1) // CHUNK
-        self.n_chunks = self.chunks_x * self.chunks_y
-        self.max_local = (self.n_chunks + self.world - 1) // self.world
+        self.n_chunks = int(lib.rt_chunk_count(self.width, self.height))
+        self.max_local = int(lib.rt_max_local_chunk_count(self.width, self.height, self.world))
+        self._lists = []
+        for rank in range(self.world):
+            n = int(lib.rt_local_chunk_count(self.width, self.height, rank, self.world))
+            buf = (C.c_int32 * max(n, 1))()
+            assert lib.rt_local_chunk_list(self.width, self.height, rank, self.world, buf, n) == n
+            self._lists.append([int(buf[i]) for i in range(n)])
 
     def chunk_ids(self, rank):
-        return list(range(rank, self.n_chunks, self.world))
+        return self._lists[rank]
 
     def n_local(self, rank):
-        return len(self.chunk_ids(rank))
+        return len(self._lists[rank])
+
+    def owner_slot(self, chunk):
+        """(rank, slot) of a global chunk index."""
+        from .native import lib
+        rank = int(lib.rt_chunk_owner(self.width, self.height, self.world, chunk))
+        return rank, self._lists[rank].index(chunk)
 
     def chunk_origin(self, chunk):
         return (chunk % self.chunks_x) * CHUNK, (chunk // self.chunks_x) * CHUNK
@@ -52,11 +70,12 @@ def untile(all_tiles, width, height, world):
     """(world, max_local, 32*32*3) rank-major gathered tiles -> (H, W, 3) image (what rt_untile does)."""
     part = FramePartition(width, height, world)
     image = np.zeros((height, width, 3), np.uint8)
-    for c in range(part.n_chunks):
-        x0, y0 = part.chunk_origin(c)
-        t = np.asarray(all_tiles[c % world][c // world]).reshape(CHUNK, CHUNK, 3)
-        hh, ww = min(CHUNK, height - y0), min(CHUNK, width - x0)
-        image[y0:y0 + hh, x0:x0 + ww] = t[:hh, :ww]
+    for rank in range(world):
+        for slot, c in enumerate(part.chunk_ids(rank)):
+            x0, y0 = part.chunk_origin(c)
+            t = np.asarray(all_tiles[rank][slot]).reshape(CHUNK, CHUNK, 3)
+            hh, ww = min(CHUNK, height - y0), min(CHUNK, width - x0)
+            image[y0:y0 + hh, x0:x0 + ww] = t[:hh, :ww]
     return image
 
 

@@ -100,6 +100,9 @@ def _declare(d):
     d.rt_set_camera.argtypes = [vp, P(abi.Camera)]
     d.rt_chunk_count.argtypes = [C.c_int32, C.c_int32]
     d.rt_local_chunk_count.argtypes = [C.c_int32] * 4
+    d.rt_chunk_owner.argtypes = [C.c_int32] * 4
+    d.rt_max_local_chunk_count.argtypes = [C.c_int32] * 3
+    d.rt_local_chunk_list.argtypes = [C.c_int32] * 4 + [P(C.c_int32), C.c_int32]
     d.rt_render_accumulate.argtypes = [vp, P(abi.RT_Render_Params), vp, vp]
     d.rt_resolve.argtypes = [P(abi.RT_Render_Params), vp, vp, vp, vp, vp]
     d.rt_untile.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]

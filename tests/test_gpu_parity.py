@@ -275,8 +275,7 @@ def test_partition_and_untile_match_single_gpu(rt):
     d = rt.lib.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
-        n_chunks = rt.lib.rt_chunk_count(w, h)
-        max_local = (n_chunks + world - 1) // world
+        max_local = rt.lib.rt_max_local_chunk_count(w, h, world)
         all_tiles = torch.zeros((world, max_local, 1024 * 3), dtype=torch.uint8, device="cuda")
         for rank in range(world):
             accum = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda")

@@ -1,10 +1,11 @@
 """Multi-process path on CPU: world_size 2 and 3 with gloo.
 
-Each rank owns chunks c % world == rank (raytracing_c_amd/multi_gpu.py), fills its compact tile
+Each rank owns the chunks rt_chunk_owner() gives it (lattice partition, include/rt_hip.h), fills its compact tile
 buffer, ONE all-gather moves the tiles, untile() rebuilds the frame.  The GPU path runs the same
 FramePartition / gather_tiles code with RCCL; rt_resolve / rt_untile (HIP) implement the two
 layouts that extract_tiles() / untile() state in numpy (checked on the GPU in test_gpu_parity.py).
 """
+import ctypes as C
 import os
 import socket
 
@@ -63,8 +64,36 @@ def test_partition_is_balanced_for_headline_frame():
     from raytracing_c_amd.multi_gpu import FramePartition
     part = FramePartition(1920, 1080, 8)
     counts = [part.n_local(r) for r in range(8)]
-    assert sum(counts) == 2040 and max(counts) - min(counts) <= 1
+    assert sum(counts) == 2040 and max(counts) - min(counts) <= 2 and max(counts) == part.max_local
     owners = np.zeros(part.n_chunks, int)
     for r in range(8):
         owners[part.chunk_ids(r)] += 1
     assert (owners == 1).all()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 6, 7, 8])
+def test_lattice_spreads_every_chunk_row_and_column_over_all_ranks(world):
+    """rank = (cx + B cy) mod world with B coprime to world: `world` consecutive chunks of any row or column have
+    `world` different owners, so a narrow expensive structure (the helmet's centre columns) cannot land on few ranks."""
+    import raytracing_c_amd as rt
+    w, h = 1920, 1080
+    cx_n, cy_n = 60, 34
+    own = np.array([rt.lib.rt_chunk_owner(w, h, world, c) for c in range(cx_n * cy_n)]).reshape(cy_n, cx_n)
+    assert own.min() == 0 and own.max() == world - 1
+    for y in range(cy_n):
+        for x0 in range(0, cx_n - world + 1, 7):
+            assert len(set(own[y, x0:x0 + world])) == world
+    for x in range(cx_n):
+        for y0 in range(0, cy_n - world + 1, 5):
+            assert len(set(own[y0:y0 + world, x])) == world
+    assert rt.lib.rt_chunk_owner(w, h, world, -1) == -1 and rt.lib.rt_chunk_owner(w, h, world, cx_n * cy_n) == -1
+    # chunk lists are ascending and consistent with the owner function
+    part_lists = []
+    for r in range(world):
+        n = rt.lib.rt_local_chunk_count(w, h, r, world)
+        buf = (C.c_int32 * n)()
+        assert rt.lib.rt_local_chunk_list(w, h, r, world, buf, n) == n
+        ids = list(buf)
+        assert ids == sorted(ids) and all(own.reshape(-1)[c] == r for c in ids)
+        part_lists.append(n)
+    assert max(part_lists) == rt.lib.rt_max_local_chunk_count(w, h, world)

@@ -45,10 +45,13 @@ for s in (256, 128, 64, 32, 16, 8):
 for world in (2, 4, 8):
     worst = 0
     tot = 0
+    per = []
     for rank in range(world):
         ms, rays = run(256, rank, world)
         worst = max(worst, ms)
         tot += rays
+        per.append((ms, rays))
+    print(f"  world {world} per rank: " + "  ".join(f"{m:.2f} ms/{r / 1e6:.1f} Mray" for m, r in per), flush=True)
     print(f"samples  256 world {world}: slowest rank {worst:8.3f} ms -> {tot/worst/1e3:8.1f} Mray/s aggregate if ranks ran in parallel", flush=True)
 for slab in (4, 8, 16, 32):
     ms, rays = run(256, 3, 8, slab)
