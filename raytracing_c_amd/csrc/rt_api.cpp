@@ -180,6 +180,10 @@ static void free_device_scene(RT_Device_Scene *d) {
   (void)hipFree(d->mats);
   (void)hipFree(d->textures);
   (void)hipFree(d->texels);
+  (void)hipFree(d->cost[0]);
+  (void)hipFree(d->cost[1]);
+  (void)hipFree(d->order);
+  (void)hipFree(d->hist);
   delete d;
 }
 
