@@ -6,13 +6,14 @@
  * (SURVEY.md section 8f #2).  Same layout, same split rule, with two defect
  * fixes that include/rt_scene.h documents (early-leaf chain, depth 0) and two
  * choices the reference leaves open: the sort is a STABLE merge sort (codin
- * sort_slice_by is unspecified) and the build is single threaded (the
- * reference's 12 builder threads write disjoint node slots, so the result does
- * not depend on threading).
+ * sort_slice_by is unspecified); the subtrees below the root are built by one
+ * thread each (the reference's 12 builder threads likewise write disjoint node
+ * slots, so the result does not depend on threading).
  */
 #include "../../include/rt_scene.h"
 #include "../../include/rt_math.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -163,6 +164,15 @@ static isize bvh_partition_triangles(isize n_triangles, isize per_child) {
 
 typedef struct { Triangle *data; isize len; } Tri_Span;
 
+typedef struct {
+  Scene       *scene;
+  Triangle    *tris;
+  isize        count, depth;
+  BVH_Index    index;
+  Sort_Buffers sb;
+} Build_Job;
+static void *build_job_run(void *arg);
+
 /* scene.c:311-414: fixed-capacity split of `tris` into at most 8 children of
  * capacity 8^depth triangles each; `depth` = internal levels at and below
  * `index` (0 = `index` is a leaf group) */
@@ -227,9 +237,39 @@ static void bvh_build(Scene *scene, Triangle *tris, isize count, isize depth, BV
     aabb_triangle_slice(finished[i].data, finished[i].len, &aabb);
     node.min_x[i] = aabb.min.x; node.min_y[i] = aabb.min.y; node.min_z[i] = aabb.min.z;
     node.max_x[i] = aabb.max.x; node.max_y[i] = aabb.max.y; node.max_z[i] = aabb.max.z;
-    bvh_build(scene, finished[i].data, finished[i].len, depth - 1, index * RT_BVH_WIDTH + 1 + (BVH_Index)i, sb);
   }
   scene->bvh.nodes.data[index] = node;
+
+  /* The children own disjoint triangle ranges, node slots and leaf groups, so below the root they are built by one
+   * thread each (the reference runs 12 builder threads, scene.c:244-309); the result does not depend on threading. */
+  if (index == 0 && depth >= 2 && count >= 2048) {
+    pthread_t th[RT_BVH_WIDTH];
+    Build_Job jobs[RT_BVH_WIDTH];
+    bool      started[RT_BVH_WIDTH];
+    for (isize i = 0; i < n_finished; i++) {
+      Build_Job *j = &jobs[i];
+      j->scene = scene; j->tris = finished[i].data; j->count = finished[i].len; j->depth = depth - 1;
+      j->index = index * RT_BVH_WIDTH + 1 + (BVH_Index)i;
+      j->sb.keys    = (Sort_Key *)malloc((size_t)j->count * sizeof(Sort_Key));
+      j->sb.tmp     = (Sort_Key *)malloc((size_t)j->count * sizeof(Sort_Key));
+      j->sb.scratch = (Triangle *)malloc((size_t)j->count * sizeof(Triangle));
+      started[i] = j->sb.keys && j->sb.tmp && j->sb.scratch && pthread_create(&th[i], NULL, build_job_run, j) == 0;
+      if (!started[i]) bvh_build(scene, j->tris, j->count, j->depth, j->index, sb);      /* fall back to this thread */
+    }
+    for (isize i = 0; i < n_finished; i++) {
+      if (started[i]) pthread_join(th[i], NULL);
+      free(jobs[i].sb.keys); free(jobs[i].sb.tmp); free(jobs[i].sb.scratch);
+    }
+    return;
+  }
+  for (isize i = 0; i < n_finished; i++)
+    bvh_build(scene, finished[i].data, finished[i].len, depth - 1, index * RT_BVH_WIDTH + 1 + (BVH_Index)i, sb);
+}
+
+static void *build_job_run(void *arg) {
+  Build_Job *j = (Build_Job *)arg;
+  bvh_build(j->scene, j->tris, j->count, j->depth, j->index, &j->sb);
+  return NULL;
 }
 
 /* scene.c:416-426.  Sorts a private copy of the input (the reference sorts the
