@@ -285,6 +285,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
+                         "valu": traffic[0].get("valu") if traffic else None,
                          "traffic_source": f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "separate passes; 2 x FETCH_SIZE + WRITE_SIZE, x 1024)" if traffic else None,
                          "kernel": "rt_path_kernel_sched<16, true> (RT_KERNEL=3 default)", "launches_averaged": int(n_launches.value),
@@ -292,7 +293,7 @@ def main():
                          "bytes_per_ray": b_ray,
                          "note": "achieved = algorithmic scene bytes (192 N + 288 L + 112 H + 48 X + 12 M per ray, "
                                  "counters from the kernel) / mean launch time; the 60 MB scene is cache "
-                                 "resident, so measured HBM traffic is ~1.5 % of the algorithmic bytes"},
+                                 "resident, so measured HBM traffic is ~2 % of the algorithmic bytes; what binds the kernel is VALU issue + latency at 4 waves per SIMD (`valu`: PMC counters of the same profile)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)

@@ -85,6 +85,17 @@ def main(tag):
     if "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters:
         lines += [f"Mean active lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) "
                   f"= {counters['SQ_THREAD_CYCLES_VALU']/(64*counters['SQ_ACTIVE_INST_VALU']):.2f}", ""]
+    if traffic and "SQ_INSTS_VALU" in counters and "GRBM_GUI_ACTIVE" in counters:
+        # VALU issue: a wave64 fp32 instruction occupies its SIMD for 2 cycles (128 fp32 lanes per CU = 4 SIMDs x 32);
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs
+        simd_cycles = counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        traffic["valu"] = {"wave_insts": counters["SQ_INSTS_VALU"],
+                           "issue_frac": 2.0 * counters["SQ_INSTS_VALU"] / simd_cycles,
+                           "active_lane_frac": counters["SQ_THREAD_CYCLES_VALU"] / (64 * counters["SQ_ACTIVE_INST_VALU"])
+                           if "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters else None,
+                           "waves_per_simd": 4}
+        lines += [f"VALU issue = 2 cycles x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = "
+                  f"**{traffic['valu']['issue_frac']:.2f}** of the SIMD cycles of the launch", ""]
     open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
     if traffic:
         json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
