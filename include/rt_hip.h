@@ -134,9 +134,11 @@ extern int rt_render_frame(Scene const *scene, Image const *image, isize samples
  * (read back synchronously). */
 extern int rt_get_counters(RT_Counters *out);
 
-/* Diagnostic kernel only (env RT_KERNEL=4): 8 pairs (times a block ran, lanes it ran with) for
- * shade, environment, regenerate, leaf (uniform), leaf (per lane), node (uniform), node (per lane), pop. */
-extern int rt_get_sched_stats(u64 out[16]);
+/* Diagnostic kernel only (env RT_KERNEL=4): out[0..15] = 8 pairs (times a block ran, lanes it ran with) for
+ * shade, environment, regenerate, leaf (uniform), leaf (per lane), node (uniform), node (per lane), pop;
+ * out[16..23] = shader-clock cycles the waves spent in S blocks with shading (16), S blocks without (17), leaf
+ * blocks (19), node blocks (21), pop loops (23), summed over waves; out[24] = cycles of the whole wave loops. */
+extern int rt_get_sched_stats(u64 out[32]);
 /* ... and per wave (start tick, end tick, items) of the last diagnostic launch; ticks are 10 ns.  Returns the wave count. */
 extern int rt_get_wave_times(u64 *out, i32 max_waves);
 

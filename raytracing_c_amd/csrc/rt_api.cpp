@@ -676,18 +676,6 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     int v = atoi(e);
     if (v >= 1 && v <= 64) K.sched_thresh = v;
   }
-  K.sched_split = 0;     // measured on helmet 1080p: one combined block at 48 lanes beats every split setting by 2-4 %
-  if (const char *e = getenv("RT_SCHED_SPLIT")) K.sched_split = atoi(e) != 0;
-  K.pop_iters = 1 << 30;     // measured: resolving every pop before the next block (56.8 ms) beats 1 (65.7), 2 (59.3), 4 (57.1) rounds
-  if (const char *e = getenv("RT_POP_ITERS")) {
-    int v = atoi(e);
-    if (v >= 1) K.pop_iters = v;
-  }
-  K.sched_thresh_shade = 24;
-  if (const char *e = getenv("RT_SCHED_THRESH_SHADE")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= 64) K.sched_thresh_shade = v;
-  }
   // dynamic LDS per workgroup: per wave (perm stack: depth x 256 B, accumulator tile: 1536 B) and, for
   // variant 3, as many leading BVH nodes (level order) as fit in the 160 KB of a CU at 208 B each
   const int lds_limit = 160 * 1024;
@@ -917,13 +905,13 @@ static float timed_slot_ms(size_t slot) {
 
 // Block statistics of the diagnostic kernel (RT_KERNEL=4): 8 pairs (executions, lanes) for
 // shade, environment, regenerate, leaf-scalar, leaf-vector, node-scalar, node-vector, pop.
-extern "C" int rt_get_sched_stats(u64 out[16]) {
+extern "C" int rt_get_sched_stats(u64 out[32]) {
   std::lock_guard<std::mutex> lock(g_mutex);
   if (ensure_device() != 0 || !out) return -1;
   unsigned long long c[RT_N_COUNTERS];
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(c, g_ws.counters, sizeof c, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 16; i++) out[i] = c[8 + i];
+  for (int i = 0; i < 32; i++) out[i] = c[8 + i];
   return 0;
 }
 

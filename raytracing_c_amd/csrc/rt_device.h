@@ -30,7 +30,7 @@
 #define RT_TILE      8       /* work item = 8x8 pixel tile x sample slab */
 #define RT_TILE_PIX  64
 
-#define RT_N_COUNTERS 24     /* 0..6 ray counters; 8..23 block statistics of the diagnostic kernel */
+#define RT_N_COUNTERS 40     /* 0..6 ray counters; 8..23 block statistics of the diagnostic kernel; 24..39 its cycle sums */
 
 /* triangle record, 28 floats:
  *  [0..2] face normal      [3]  material id (int bits)
@@ -80,10 +80,7 @@ typedef struct {
   int32_t slab_shift;          /* samples per work item = 1 << slab_shift */
   int32_t n_slabs;             /* ceil((sample_end - sample_first) / slab) */
   int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
-  int32_t sched_thresh;        /* lanes waiting for environment/regenerate that trigger it */
-  int32_t sched_thresh_shade;  /* lanes waiting for shading that trigger it           */
-  int32_t pop_iters;           /* pop rounds after each traversal block               */
-  int32_t sched_split;         /* 1: shading scheduled apart from environment+regen   */
+  int32_t sched_thresh;        /* lanes waiting for shade / environment / regeneration that trigger that block */
   int32_t sample_major;        /* work-item index -> (pixel, sample) mapping         */
   int32_t n_lds_nodes;         /* BVH nodes [0, n) are also in the workgroup's LDS   */
   /* outputs */

@@ -849,8 +849,6 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   const int item_paths = RT_TILE_PIX << P.slab_shift;
   const int leaf_level = P.depth - 1;
   const int thresh = P.sched_thresh;
-  const int thresh_shade = P.sched_thresh_shade;
-  const int pop_iters = P.pop_iters;
   // diagnostic build only (STATS): how often each block ran and with how many lanes; wave-uniform
   const unsigned long long t_wave_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
   uint32_t n_items_done = 0;
@@ -858,6 +856,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 #pragma unroll
   for (int i = 0; i < 16; i++) st[i] = 0;
 #define STAT(slot, lanes) do { if (STATS) { st[2 * (slot)] += 1; st[2 * (slot) + 1] += (uint32_t)(lanes); } } while (0)
+  // ... and the shader-clock cycles the wave spent in each kind of block (wall time of the wave, other waves' issue included)
+  unsigned long long cyc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) cyc[i] = 0ull;
+  unsigned long long t_blk = 0ull;
+  const unsigned long long t_loop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#define CYC_BEGIN() do { if (STATS) t_blk = __builtin_amdgcn_s_memtime(); } while (0)
+#define CYC_END(slot) do { if (STATS) cyc[slot] += __builtin_amdgcn_s_memtime() - t_blk; } while (0)
 
   for (;;) {
     // ---- dequeue one work item (wave-uniform).  Items are small (8x8 pixels x 16 samples by default):
@@ -901,24 +907,18 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
       const int nH = (int)__popcll(__ballot(phase == PH_HIT));
       const int nE = (int)__popcll(__ballot(phase == PH_MISS || (can_regen && phase == PH_NEED)));
-      const bool popping = __any(phase == PH_POP);   // lanes still between two traversal blocks (see the pop loop below)
-      if (nN + nL + nH + nE == 0 && !popping) break;          // every lane idle and the item has no paths left
+      // (no lane is between blocks here: the pop loop at the end of an iteration runs until every lane has its next block)
+      if (nN + nL + nH + nE == 0) break;          // every lane idle and the item has no paths left
 
-      // Block choice.  Shading is by far the most expensive block (~2 200 VALU instructions against ~330 for
-      // a node), so it gets its own threshold: it runs when thresh_shade lanes wait for it; environment +
-      // regeneration (~750) when thresh lanes wait; traversal otherwise; with nothing traversing, whatever waits.
-      const bool traversing = nN + nL > 0 || popping;
-      bool run_shade, run_env;
-      if (P.sched_split) {
-        run_shade = nH > 0 && (nH >= thresh_shade || (!traversing && nE < thresh));
-        run_env = !run_shade && nE > 0 && (nE >= thresh || !traversing);
-      } else {              // one combined block: shade + environment + regenerate once `thresh` lanes wait for any of them
-        const bool both = (nH + nE >= thresh) || !traversing;
-        run_shade = both && nH > 0;
-        run_env = both && nE > 0;
-      }
+      // Block choice: ONE combined block -- shade the hits, look up the environment for the misses, start new paths --
+      // once `thresh` lanes wait for any of that, or when nothing is traversing.  (Separate thresholds for shading
+      // and for environment + regeneration were measured and lost by 2-4 %.)
+      const bool both = (nH + nE >= thresh) || (nN + nL == 0);
+      const bool run_shade = both && nH > 0;
+      const bool run_env = both && nE > 0;
 
       if (run_shade || run_env) {
+        CYC_BEGIN();
         if (run_shade) STAT(0, nH);
         if (run_env) STAT(1, __popcll(__ballot(phase == PH_MISS)));
         if (run_env && can_regen) STAT(2, __popcll(__ballot(phase == PH_NEED)));
@@ -979,6 +979,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           child = (P.depth > 0) ? 0 : P.last_row_offset;
           phase = (P.depth > 0) ? PH_NODE : PH_LEAF;
         }
+        CYC_END(run_shade ? 0 : 1);
         continue;
       }
 
@@ -986,6 +987,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         // only lanes between blocks: fall through to the pop loop
       } else if (nL >= nN) {
         // ================= LEAF =================
+        CYC_BEGIN();
         if (phase == PH_LEAF) {
           cn.leaves += 1;
           int  g = child - P.last_row_offset;
@@ -996,8 +998,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           if (got) dirty = 0xFFFFFFFFu;
           phase = PH_POP;
         }
+        CYC_END(3);
       } else {
         // ================= NODE =================
+        CYC_BEGIN();
         const bool all_fast = __ballot(phase == PH_NODE && !ray.fast) == 0;
         if (phase == PH_NODE) {
           if (level >= 0) {
@@ -1026,12 +1030,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             phase = PH_POP;
           }
         }
+        CYC_END(5);
       }
 
-      // ---- pops: after a block, at most pop_iters rounds of "take the next child / go up one level"; a lane that
-      //      needs more (several levels up, rejected children) stays in PH_POP and continues after the next block,
-      //      instead of making the whole wave spin with two dozen lanes ----
-      for (int it = 0; it < pop_iters && __any(phase == PH_POP); it++) {
+      // ---- pops: every lane that just finished a block takes its next child / goes up until it knows its next block
+      //      (bounding the rounds per iteration and letting lanes wait in PH_POP was measured: 1 round 65.7 ms, 4 rounds
+      //      57.1 ms, unbounded 56.8 ms) ----
+      CYC_BEGIN();
+      while (__any(phase == PH_POP)) {
         STAT(7, __popcll(__ballot(phase == PH_POP)));
         if (phase == PH_POP) {
           uint32_t cnt = cur >> 24;
@@ -1068,6 +1074,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           }
         }
       }
+      CYC_END(7);
     }
 
     // ---- flush the tile: lane p owns pixel p ----
@@ -1104,6 +1111,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     if (STATS) {
 #pragma unroll
       for (int i = 0; i < 16; i++) atomicAdd(P.counters + 8 + i, (unsigned long long)st[i]);
+#pragma unroll
+      for (int i = 0; i < 8; i++) atomicAdd(P.counters + 24 + i, cyc[i]);
+      atomicAdd(P.counters + 32, __builtin_amdgcn_s_memtime() - t_loop0);
       if (P.wave_times) {
         int wid = blockIdx.x * WAVES + wave;
         P.wave_times[wid * 3 + 0] = t_wave_start;
@@ -1113,6 +1123,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     }
   }
 #undef STAT
+#undef CYC_BEGIN
+#undef CYC_END
 }
 
 // ---------------------------------------------------------------------------------

@@ -44,30 +44,11 @@ def main():
                     print(f"kernel {kv} thresh {th:2d} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_KERNEL")
         os.environ.pop("RT_SCHED_THRESH")
-    if "shade" in knobs:
-        os.environ["RT_SCHED_SPLIT"] = "0"
+    if "thresh" in knobs:   # lanes waiting for the shade / environment / regenerate block that trigger it
         for th in (32, 40, 48, 56):
             os.environ["RT_SCHED_THRESH"] = str(th)
-            print(f"combined S thresh {th:2d}: {run(16, 4):8.3f} ms", flush=True)
-        os.environ["RT_SCHED_SPLIT"] = "1"
-        for ts in (16, 24, 32):
-            os.environ["RT_SCHED_THRESH_SHADE"] = str(ts)
-            for th in (24, 32, 40, 48):
-                os.environ["RT_SCHED_THRESH"] = str(th)
-                print(f"thresh_shade {ts:2d} thresh {th:2d}: {run(16, 4):8.3f} ms", flush=True)
-        os.environ.pop("RT_SCHED_THRESH_SHADE")
+            print(f"S thresh {th:2d}: {run(0, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_SCHED_THRESH")
-    if "pop" in knobs:
-        for pi in (1, 2, 3, 4, 6, 100):
-            os.environ["RT_POP_ITERS"] = str(pi)
-            for th in (40, 48, 56):
-                os.environ["RT_SCHED_THRESH"] = str(th)
-                print(f"pop_iters {pi:3d} thresh {th}: {run(16, 4):8.3f} ms", flush=True)
-        os.environ.pop("RT_POP_ITERS")
-        os.environ.pop("RT_SCHED_THRESH")
-    if "slab16" in knobs:
-        for slab in (8, 16):
-            print(f"slab {slab:2d}: {run(slab, 4):8.3f} ms", flush=True)
     if "ldsn" in knobs:     # how many leading BVH nodes need to be in LDS
         for nl in (0, 9, 73, 105, 150, 200, 290, 100000):
             os.environ["RT_LDS_NODES"] = str(nl)

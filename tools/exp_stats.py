@@ -31,7 +31,7 @@ for env in ({},) if SLAB else ({}, {"RT_SCHED_THRESH": "32"}, {"RT_SCHED_THRESH"
     accum.zero_()
     assert rt.lib.rt_render_accumulate(d, C.byref(p), accum.data_ptr(), None) == 0, rt.last_error()
     torch.cuda.synchronize()
-    st = (C.c_uint64 * 16)()
+    st = (C.c_uint64 * 32)()
     assert rt.lib.rt_get_sched_stats(st) == 0
     ms = rt.lib.rt_last_kernel_ms()
     tot = 0
@@ -44,5 +44,12 @@ for env in ({},) if SLAB else ({}, {"RT_SCHED_THRESH": "32"}, {"RT_SCHED_THRESH"
     print(f"--- {name} {env} kernel {ms:.2f} ms (diagnostic build) est. VALU wave-instr {tot/1e9:.2f} G")
     for n, ex, ln, avg, est in rows:
         print(f"  {n:13s} runs {ex/1e6:9.2f} M  lanes/run {avg:5.1f}  est {est/1e9:6.2f} G ({100*est/tot:4.1f} %)")
+    tot_cyc = st[24]
+    names = {16: "S blocks with shading", 17: "S blocks (environment + regeneration only)", 19: "leaf blocks", 21: "node blocks", 23: "pop loops"}
+    acc = 0
+    for i, nm in names.items():
+        acc += st[i]
+        print(f"  cycles in {nm:45s} {100 * st[i] / max(tot_cyc, 1):5.1f} % of the wave time")
+    print(f"  cycles in scheduling / dequeue / flush (rest)            {100 * (tot_cyc - acc) / max(tot_cyc, 1):5.1f} %")
     for k in env:
         os.environ.pop(k)
