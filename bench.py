@@ -7,8 +7,9 @@ helmet, 1920x1080, 256 spp, 8 bounces (configs[2]; scene = assets/helmet.glb, th
 self-contained form of models/helmet.gltf).  Scene, textures and background are resident in
 HBM before the timed region; the region covers accumulation-buffer clear, the path kernel,
 resolve to u8, the framebuffer tile gather over RCCL (N > 1), untile and the D2H copy of the
-finished image on rank 0 -- the reference's own timed region is thread spawn -> finish
-(driver.c:791-821).
+finished image on rank 0 (on a copy stream, double-buffered: it overlaps the next frame's kernel;
+the final synchronisation waits for the last copy) -- the reference's own timed region is thread
+spawn -> finish (driver.c:791-821).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -190,15 +191,26 @@ def main():
     dev = torch.device("cuda", local_rank)
     max_local = FramePartition(w, h, world).max_local
     accum = torch.zeros((h, w, 3), dtype=torch.int64, device=dev)
-    image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    # the finished frame leaves through a copy stream (double-buffered), so the 6 MB device->host copy of frame k
+    # overlaps the path kernel of frame k+1 instead of sitting between two kernels
+    images = [torch.zeros((h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    host_images = [torch.zeros((h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ev_frame = [torch.cuda.Event() for _ in range(2)]
+    ev_copied = [torch.cuda.Event() for _ in range(2)]
+    frame_no = [0]
     tiles = torch.zeros((max_local, 1024 * 3), dtype=torch.uint8, device=dev)
     multi = world > 1 or force_dist
     all_tiles = torch.zeros((world, max_local, 1024 * 3), dtype=torch.uint8, device=dev) if multi else None
-    host_image = torch.zeros((h, w, 3), dtype=torch.uint8).pin_memory()
     params = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, rank, world, args.slab, 0)
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
+        buf = frame_no[0] & 1
+        frame_no[0] += 1
+        image = images[buf]
+        if rank == 0 and frame_no[0] > 2:
+            torch.cuda.current_stream().wait_event(ev_copied[buf])      # its previous contents have reached the host
         accum.zero_()
         if rt.lib.rt_render_accumulate(dscene, C.byref(params), accum.data_ptr(), stream) != 0:
             raise RuntimeError(rt.last_error())
@@ -218,7 +230,11 @@ def main():
                 if rt.lib.rt_untile(w, h, world, all_tiles.data_ptr(), image.data_ptr(), stream) != 0:
                     raise RuntimeError(rt.last_error())
         if rank == 0:
-            host_image.copy_(image, non_blocking=True)
+            ev_frame[buf].record()
+            copy_stream.wait_event(ev_frame[buf])
+            with torch.cuda.stream(copy_stream):
+                host_images[buf].copy_(image, non_blocking=True)
+                ev_copied[buf].record()
 
     def sync():
         torch.cuda.synchronize()
@@ -299,7 +315,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)
         if args.save:
             from PIL import Image
-            Image.fromarray(host_image.numpy()).save(args.save)
+            Image.fromarray(host_images[(frame_no[0] - 1) & 1].numpy()).save(args.save)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
