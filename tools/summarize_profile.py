@@ -19,7 +19,7 @@ def main(tag):
     stats = sorted(glob.glob(os.path.join(src, f"prof_{tag}_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]
     kernel_avg_ms = None
     if stats:
-        lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1`", "",
+        lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 9 --warmup 1`", "",
                   "| kernel | calls | total ms | average ms | % | min ms | max ms |", "|---|---|---|---|---|---|---|"]
         for r in csv.DictReader(open(stats[0])):
             name = r["Name"].split("(")[0][:60]
