@@ -83,8 +83,6 @@ static u32        g_seed = 0x1234ABCDu;
 struct Workspace {
   unsigned long long *accum = nullptr;
   size_t              accum_elems = 0;
-  unsigned long long *counters = nullptr;   // RT_N_COUNTERS
-  uint32_t           *work_head = nullptr;
   uint8_t            *image = nullptr;
   float              *linear = nullptr;
   size_t              image_pixels = 0;
@@ -96,6 +94,7 @@ struct Workspace {
 };
 #define RT_MAX_TIMED 256
 static Workspace g_ws;
+static unsigned long long *g_last_counters = nullptr;   // counters of the most recent path-kernel launch
 
 static int ensure_device() {
   if (g_device_ready) return 0;
@@ -110,8 +109,6 @@ static int ensure_device() {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, g_device));
   g_num_cus = prop.multiProcessorCount;
-  HIP_TRY(hipMalloc(&g_ws.counters, RT_N_COUNTERS * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(&g_ws.work_head, 64));
   g_device_ready = true;
   return 0;
 }
@@ -162,6 +159,9 @@ struct RT_Device_Scene {
   // fingerprint of the host scene this was built from
   const void  *fp_nodes = nullptr, *fp_tris = nullptr, *fp_bg = nullptr;
   int64_t      fp_len = 0, fp_depth = 0;
+  // launch state of this device scene: two device scenes can have launches in flight on two streams at once
+  unsigned long long *counters = nullptr;      // RT_N_COUNTERS
+  uint32_t           *work_head = nullptr;
   // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
   uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
   uint32_t    *order = nullptr, *hist = nullptr;
@@ -180,6 +180,9 @@ static void free_device_scene(RT_Device_Scene *d) {
   (void)hipFree(d->mats);
   (void)hipFree(d->textures);
   (void)hipFree(d->texels);
+  if (g_last_counters == d->counters) g_last_counters = nullptr;
+  (void)hipFree(d->counters);
+  (void)hipFree(d->work_head);
   (void)hipFree(d->cost[0]);
   (void)hipFree(d->cost[1]);
   (void)hipFree(d->order);
@@ -377,6 +380,12 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   if (bg < 0) { rt_fail("rt_scene_upload: background Image is unusable (need u8, >=3 components)"); return nullptr; }
 
   RT_Device_Scene *d = new RT_Device_Scene();
+  if (hipMalloc((void **)&d->counters, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **)&d->work_head, 64) != hipSuccess) {
+    rt_fail("rt_scene_upload: out of device memory");
+    free_device_scene(d);
+    return nullptr;
+  }
   if (upload(&d->nodes, nodes, &d->bytes) || upload(&d->leaves, leaves, &d->bytes) ||
       upload(&d->tris, tris, &d->bytes) || upload(&d->mats, mats, &d->bytes) ||
       upload(&d->textures, pool.descs, &d->bytes) || upload_textures(pool, &d->texels, &d->bytes)) {
@@ -644,8 +653,8 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   if (n_work > 0x7fffffff) return rt_fail("too many work items (%lld)", (long long)n_work);
   K->n_work = (int32_t)n_work;
   K->accum = (unsigned long long *)d_accum;
-  K->counters = g_ws.counters;
-  K->work_head = g_ws.work_head;
+  K->counters = d->counters;
+  K->work_head = d->work_head;
   return 0;
 }
 
@@ -656,8 +665,9 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   if (!d || !d_accum) return rt_fail("rt_render_accumulate: NULL scene or accumulation buffer");
   RT_KParams K;
   if (fill_kparams(&K, d, cam, p, d_accum) != 0) return -1;
-  HIP_TRY(hipMemsetAsync(g_ws.counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
-  HIP_TRY(hipMemsetAsync(g_ws.work_head, 0, 64, stream));
+  HIP_TRY(hipMemsetAsync(d->counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(d->work_head, 0, 64, stream));
+  g_last_counters = d->counters;
   if (K.n_work == 0) return 0;
   // persistent grid: 16 waves per CU (4 per SIMD at <= 128 VGPRs), never more waves than work items
   int waves_per_cu = 16;
@@ -885,7 +895,8 @@ extern "C" int rt_get_counters(RT_Counters *out) {
   if (ensure_device() != 0) return -1;
   unsigned long long c[RT_N_COUNTERS];
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(c, g_ws.counters, sizeof c, hipMemcpyDeviceToHost));
+  if (!g_last_counters) { memset(c, 0, sizeof c); } else
+  HIP_TRY(hipMemcpy(c, g_last_counters, sizeof c, hipMemcpyDeviceToHost));
   out->paths = c[0];
   out->rays = c[1];
   out->node_visits = c[2];
@@ -910,7 +921,8 @@ extern "C" int rt_get_sched_stats(u64 out[32]) {
   if (ensure_device() != 0 || !out) return -1;
   unsigned long long c[RT_N_COUNTERS];
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(c, g_ws.counters, sizeof c, hipMemcpyDeviceToHost));
+  if (!g_last_counters) { memset(c, 0, sizeof c); } else
+  HIP_TRY(hipMemcpy(c, g_last_counters, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 32; i++) out[i] = c[8 + i];
   return 0;
 }
