@@ -722,6 +722,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
               tint = rt_v3_make(1, 1, 1);
               emis = rt_v3_make(0, 0, 0);
               cn.paths += 1;
+            } else if (s < P.sample_end && x < P.width && y < P.height) {
+              cn.paths += 1;      // max_bounces == 0: the path exists and is black (the loop of raytracer.c:512 runs zero times)
             }
           }
         }
@@ -963,6 +965,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                 emis = rt_v3_make(0, 0, 0);
                 cn.paths += 1;
                 start = true;
+              } else if (s < P.sample_end && x < P.width && y < P.height) {
+                cn.paths += 1;    // max_bounces == 0: the path exists and is black (the loop of raytracer.c:512 runs zero times)
               }
             }
           }

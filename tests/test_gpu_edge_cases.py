@@ -38,7 +38,7 @@ def test_empty_scene_is_all_background(rt, oracle):
 
 
 @pytest.mark.parametrize("w,h,s,b", [(1, 1, 1, 1), (1, 1, 5, 8), (3, 2, 2, 1), (33, 1, 4, 4), (1, 33, 4, 4), (8, 8, 1, 8),
-                                     (65, 31, 1, 1)])
+                                     (65, 31, 1, 1), (8, 8, 2, 0)])
 def test_tiny_and_ragged_frames(rt, oracle, w, h, s, b):
     from raytracing_c_amd.configs import load_config
     from tests import _oracle

@@ -34,7 +34,10 @@ def main():
         return rt.lib.rt_kernel_timing_mean_ms(C.byref(n))
 
     run(64, 4)
-    knobs = os.environ.get("RT_EXP", "slab,bpc").split(",")
+    knobs = os.environ.get("RT_EXP", "auto,slab").split(",")
+    if "auto" in knobs:     # the library's own choice of the item size (what bench.py runs); used by tools/exp_ab.sh
+        print(f"slab auto: {run(0, 4):8.3f} ms", flush=True)
+        print(f"slab auto: {run(0, 4):8.3f} ms", flush=True)
     if "kernel" in knobs:
         for kv in (1, 2, 3):
             os.environ["RT_KERNEL"] = str(kv)
@@ -61,11 +64,8 @@ def main():
                 print(f"sample_major {sm} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_SAMPLE_MAJOR")
     if "slab" in knobs:
-        for slab in (8, 16, 32, 64, 128, 256):
-            print(f"slab {slab:4d} bpc 4: {run(slab, 4):8.3f} ms", flush=True)
-    if "bpc" in knobs:
-        for bpc in (1, 2, 3, 4, 6, 8):
-            print(f"slab   64 bpc {bpc}: {run(64, bpc):8.3f} ms", flush=True)
+        for slab in (4, 8, 16, 32, 64, 128, 256):
+            print(f"slab {slab:4d}: {run(slab, 4):8.3f} ms", flush=True)
     c = rt.render.get_counters()
     print("rays", c.rays, "Mray/s at last run n/a")
 
