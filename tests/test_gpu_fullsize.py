@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's full sizes.
 
-The oracle cannot render 530 M paths in a test, so full frames are checked through properties that do
-not depend on size: bit-exact parity on WINDOWS of the full frame (the oracle renders only the window,
+Config #3 (the bench workload) is compared with the oracle in full; the bigger configs (#4, #5: 1 and 8.5 G paths)
+are checked through properties that do not depend on size: bit-exact parity on WINDOWS of the full frame (the oracle renders only the window,
 with the full frame's width/height/spp so rays, seeds and jitter are the full frame's), additivity of
 the fixed-point accumulation over sample ranges, independence from the GPU partition and from
 scheduling, exact path counts, and a checksum of checksums.
@@ -76,6 +76,34 @@ def test_config3_full_frame_windows_match_oracle(rt, helmet):
     assert abs(lum[450:650, 900:1000].mean() / lum[:100].mean() - 1) > 0.2
 
 
+def _host_threads():
+    import os
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            threads = max(1, min(threads, int(round(int(q[0]) / int(q[1])))))
+    except OSError:
+        pass
+    return min(threads, 64)
+
+
+def test_config3_entire_frame_matches_oracle(rt, helmet):
+    """BASELINE.json configs[2] in full -- 1920x1080, 256 spp, 8 bounces, 530.8 M paths, 642.5 M rays: every one of the
+    6.2 M fixed-point radiance sums, the u8 image and all seven counters equal the CPU oracle's.  (The oracle needs
+    about 8 s for the frame on the 16 host CPUs of a GPU box; threads = the CPUs this process may use.)"""
+    from tests import _oracle
+    w, h, s, b = 1920, 1080, 256, 8
+    want = _oracle.render(helmet.hs, w, h, s, b, n_threads=_host_threads())
+    got = rt.render_frame(helmet.hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    c = got["counters"]
+    for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+        assert want["counters"][k] == getattr(c, k), k
+    assert c.paths == w * h * s == 530841600 and c.rays == 642492860
+
+
 def test_config3_additivity_partition_and_determinism(rt, helmet):
     """Fixed-point sums are exact: sample ranges add up, 8 ranks' chunks add up, reruns are identical."""
     w, h, s, b = 1920, 1080, 32, 8          # full frame, reduced spp: the properties are size independent
@@ -112,6 +140,23 @@ def test_config4_tower_window(rt):
         assert np.array_equal(acc[y0:y1, x0:x1], want[y0:y1, x0:x1])
     finally:
         f.close()
+
+
+def test_config4_entire_frame_matches_oracle(rt):
+    """BASELINE.json configs[3] in full on one GPU -- tower 1920x1080, 512 spp, 12 bounces, 1.06 G paths: all radiance
+    sums, the image and the counters equal the oracle's."""
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("tower")
+    w, h, s, b = 1920, 1080, 512, 12
+    want = _oracle.render(hs, w, h, s, b, n_threads=_host_threads())
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    c = got["counters"]
+    for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+        assert want["counters"][k] == getattr(c, k), k
+    assert c.paths == w * h * s
 
 
 def test_config5_4k_window(rt, helmet):
