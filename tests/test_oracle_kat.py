@@ -469,5 +469,23 @@ def test_helmet_matches_reference_sample_render_in_framing_and_orientation():
     assert np.abs(centroid(cr) - centroid(cm)).max() < 7.0            # 128-pixel scale: within 5 % of the frame
     dr, dm = ref.astype(int).sum(-1) < 120, mine.astype(int).sum(-1) < 120
     assert np.abs(centroid(dr) - centroid(dm)).max() < 8.0
+    # ... to the pixel: left and bottom edge of the ring (its right/top side merges with HUD lines that our brighter
+    # environment lights up), and the three small yellow lamps of the upper shell, which are emissive
+    def ring_box(a):
+        m = cyan(a)
+        m[:, 60:] = False
+        ys, xs = np.nonzero(m)
+        return xs.min(), ys.max()
+    assert np.abs(np.array(ring_box(ref)) - np.array(ring_box(mine))).max() <= 1
+
+    def lamps(a):
+        r, g, b = [a[..., i].astype(int) for i in range(3)]
+        m = (r > 150) & (g > 140) & (b < 110)
+        m[64:] = False
+        return np.argwhere(m)
+    lr, lm = lamps(ref), lamps(mine)
+    assert len(lm) >= 3
+    matched = sum(1 for q in lm if np.abs(lr - q).max(axis=1).min() <= 1)
+    assert matched >= 3, (lr.tolist(), lm.tolist())                    # (y, x) at 128 x 128: (34, 101), (34, 102), (35, 37)
     # a vertical or horizontal flip of our render would move the ring far away
     assert np.abs(centroid(cr) - centroid(cyan(mine[::-1]))).max() > 15 and np.abs(centroid(cr) - centroid(cyan(mine[:, ::-1]))).max() > 15
