@@ -679,8 +679,6 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   if (n_waves > K.n_work) n_waves = K.n_work;
   int variant = 3;     // 1 plain while-while, 2 phase-scheduled, 3 phase-scheduled + top of the BVH in LDS
   if (const char *e = getenv("RT_KERNEL")) variant = atoi(e);
-  K.sample_major = 0;
-  if (const char *e = getenv("RT_SAMPLE_MAJOR")) K.sample_major = atoi(e) != 0;
   K.sched_thresh = 48;
   if (const char *e = getenv("RT_SCHED_THRESH")) {
     int v = atoi(e);

@@ -81,7 +81,6 @@ typedef struct {
   int32_t n_slabs;             /* ceil((sample_end - sample_first) / slab) */
   int32_t n_work;              /* n_local_chunks * 16 * n_slabs           */
   int32_t sched_thresh;        /* lanes waiting for shade / environment / regeneration that trigger that block */
-  int32_t sample_major;        /* work-item index -> (pixel, sample) mapping         */
   int32_t n_lds_nodes;         /* BVH nodes [0, n) are also in the workgroup's LDS   */
   /* outputs */
   unsigned long long *accum;   /* [height*width*3] 32.32 fixed point      */

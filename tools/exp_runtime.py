@@ -57,12 +57,6 @@ def main():
             os.environ["RT_LDS_NODES"] = str(nl)
             print(f"lds nodes {nl:6d}: {run(16, 4):8.3f} ms", flush=True)
         os.environ.pop("RT_LDS_NODES")
-    if "map" in knobs:
-        for sm in (0, 1):
-            os.environ["RT_SAMPLE_MAJOR"] = str(sm)
-            for slab in (4, 8, 16, 32, 64, 128, 256):
-                print(f"sample_major {sm} slab {slab:3d}: {run(slab, 4):8.3f} ms", flush=True)
-        os.environ.pop("RT_SAMPLE_MAJOR")
     if "slab" in knobs:
         for slab in (4, 8, 16, 32, 64, 128, 256):
             print(f"slab {slab:4d}: {run(slab, 4):8.3f} ms", flush=True)
