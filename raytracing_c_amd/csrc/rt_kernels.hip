@@ -63,9 +63,10 @@ __device__ __forceinline__ float4 ld4(const float *base, int idx4) {
   return reinterpret_cast<const float4 *>(base)[idx4];
 }
 
-// Wave-uniform reads go through the scalar cache: a pointer in the constant address space with a
-// uniform (SGPR) address makes hipcc emit s_load_dwordx16 instead of one vector load per lane --
-// no L1/TD return traffic and no VGPRs for the node or leaf data.
+// Scalar-cache reads: a pointer in the constant address space with a uniform (SGPR) address makes hipcc emit
+// s_load_dwordx16 instead of one vector load per lane.  Used by the plain kernel (rt_path_kernel / trace_ray) for
+// wave-uniform nodes and leaves; the scheduled kernel dropped these paths (LDS broadcast reads are faster and the
+// 48 / 72 SGPRs per node / leaf tile cost it 34 spilled SGPRs).
 typedef const float __attribute__((address_space(4))) cfloat;
 __device__ __forceinline__ cfloat *as_scalar_ptr(const float *p) { return (cfloat *)(unsigned long long)p; }
 
@@ -1016,9 +1017,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           level += 1;
           cn.nodes += 1;
           if (all_fast) {
-            // nodes of the LDS copy are read from LDS even when all lanes want the same one (a broadcast read): measured
-            // 4.4 % faster than the scalar-cache path, whose s_load latency and 48 SGPRs cost more than they save.  The
-            // scalar path remains for wave-uniform nodes outside the LDS copy.
+            // nodes of the LDS copy are read from LDS, also when all lanes want the same one (a broadcast read); nodes
+            // outside the copy come through L1/L2.  (A scalar-cache path for wave-uniform nodes was measured: slower.)
             if (LDSN && __ballot(node >= n_lds) == 0) { STAT(6, nN); cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes); }
             else { STAT(5, nN); cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes); }
           } else {
