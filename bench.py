@@ -14,6 +14,7 @@ spawn -> finish (driver.c:791-821).
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: starts the N ranks itself, see launch_ranks())
 
 Rank 0 prints ONE JSON line.  value = rays traced by all ranks per second / 1e6 (Mray/s,
 rays counted in-kernel), weak/strong: the frame is fixed, so scaling is "strong".
@@ -46,7 +47,44 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--save", default="", help="write the last frame as PNG (rank 0)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: ranks rendezvous (gloo), exchange an empty tile buffer, rank 0 prints a "
+                         "stub line -- covers the launcher and the N-rank plumbing on a CPU-only machine")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.
+    This parent has not imported torch and never touches the GPU; it is not replaced by an exec, it waits
+    for the children and exits with their status."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout:
+        txt = raw.decode("utf-8", "replace").rstrip("\n")
+        if txt.startswith("{") and line is None:
+            line = txt
+        else:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 3
+    sys.exit(rc)
 
 
 def cpu_baseline(hs, cfg, target_seconds):
@@ -109,13 +147,14 @@ def cpu_baseline(hs, cfg, target_seconds):
             "msample_per_s": w * h * spp / dt / 1e6}
 
 
-def measured_traffic(workload):
-    """HBM bytes per rt_path_kernel launch from the newest committed PMC summary of this workload
-    (profiles/*_traffic.json, written by tools/summarize_profile.py from separate rocprofv3 --pmc
-    passes of this same command).  bench.py cannot read PMC counters itself."""
+def measured_profile(workload):
+    """PMC summary of this workload (profiles/*_traffic.json, newest tag wins): HBM-side bytes, VALU
+    wave-instructions, active lanes, SIMD cycles of ONE rt_path_kernel launch, collected by separate
+    `rocprofv3 --pmc` passes of this same command (tools/profile_gpu.sh + tools/summarize_profile.py).
+    bench.py cannot read PMC counters itself: these values are REPLAYED and labelled as such."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime):
         try:
             t = json.load(open(f))
         except Exception:
@@ -125,8 +164,102 @@ def measured_traffic(workload):
     return best
 
 
+# MI355X: 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds its SIMD for 2 cycles (MI355X_MICROARCH.md,
+# Wave scheduling); 2.4 GHz is the chip's maximum clock -- the clock under load is lower, so `frac` against this
+# peak is a lower bound of the issue-slot use at the real clock (`valu.issue_frac_profiled_clock`).
+SIMDS = 256 * 4
+MAX_CLOCK_HZ = 2.4e9
+VALU_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / 2.0 / 1e9      # G wave-instructions / s
+LDS_PEAK_GBS = 256 * 128 * MAX_CLOCK_HZ / 1e9           # 128 B / clk / CU
+
+
+def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_name):
+    """What binds rt_path_kernel is VALU issue (branchy fp32, scene resident in LDS / L2 / Infinity Cache), so the
+    headline fraction is VALU wave-instructions issued / issue slots.  The HBM figures are kept beside it: measured
+    HBM-side bytes (PMC) and SURVEY 8d's algorithmic scene bytes, which are served on chip and therefore are NOT
+    an HBM rate."""
+    b_ray = tot.bytes_per_ray()
+    ksec = kernel_ms * 1e-3 if kernel_ms and kernel_ms > 0 else None
+    alg_bytes = rays_per_launch * b_ray
+    rays = max(tot.rays, 1)
+    node_bytes = 192.0 * tot.node_visits / rays * rays_per_launch
+    out = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": None,
+           "traffic": None, "kernel": variant_name, "launches_averaged": int(n_launches), "kernel_ms": kernel_ms,
+           "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+           "algorithmic": {"bytes_per_ray": b_ray, "bytes_per_launch": alg_bytes,
+                           "rate_GBps": alg_bytes / ksec / 1e9 if ksec else None,
+                           "ratio_to_hbm_peak": alg_bytes / ksec / 1e9 / HBM_PEAK_GBS if ksec else None,
+                           "note": "SURVEY 8d scene bytes (192 N + 288 L + 112 H + 48 X + 12 M per ray, counters from "
+                                   "the kernel); served by LDS / L1 / L2 / Infinity Cache, NOT HBM traffic -- a ratio "
+                                   "above 1 only says the scene is cache resident"},
+           "lds": {"node_bytes_per_launch": node_bytes,
+                   "rate_GBps": node_bytes / ksec / 1e9 if ksec else None, "peak_GBps": LDS_PEAK_GBS,
+                   "frac": node_bytes / ksec / 1e9 / LDS_PEAK_GBS if ksec else None,
+                   "note": "BVH node reads (192 B per node visit) come from the workgroup's LDS copy of the tree"},
+           "l1_l2": {"bytes_per_launch": alg_bytes - node_bytes,
+                     "rate_GBps": (alg_bytes - node_bytes) / ksec / 1e9 if ksec else None,
+                     "note": "leaf tiles, shading records, texels through L1 / L2"}}
+    if prof and ksec:
+        t, fname = prof
+        out["replayed_from"] = f"profiles/{fname}"
+        out["replayed_note"] = ("traffic, valu.* and hbm.* use PMC counters of one launch of this same workload and kernel "
+                                "(separate rocprofv3 --pmc passes, committed summary); only the launch time is live")
+        hbm = t.get("hbm_bytes_per_launch")
+        out["traffic"] = hbm
+        if hbm:
+            out["hbm"] = {"achieved": hbm / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": hbm / ksec / 1e9 / HBM_PEAK_GBS, "traffic_over_algorithmic": hbm / alg_bytes,
+                          "correction": t.get("correction")}
+        v = t.get("valu") or {}
+        if v.get("wave_insts"):
+            ach = v["wave_insts"] / ksec / 1e9
+            out["achieved"] = ach
+            out["frac"] = ach / VALU_PEAK_GINST
+            lanes = v.get("active_lane_frac")
+            out["valu"] = {"wave_insts_per_launch": v["wave_insts"],
+                           "issue_frac_profiled_clock": v.get("issue_frac"),
+                           "active_lane_frac": lanes,
+                           "useful_lane_issue": (v.get("issue_frac") * lanes) if v.get("issue_frac") and lanes else None,
+                           "waves_per_simd": v.get("waves_per_simd"),
+                           "note": "issue_frac_profiled_clock = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): "
+                                   "issue slots at the clock of the profiled launch; useful = issue x active lanes"}
+    return out
+
+
+def dry_run(args, world, rank):
+    """CPU-only rehearsal of the N-rank plumbing: rendezvous, partition tables, tile exchange, MAX-over-ranks
+    timing, one line from rank 0.  No kernel runs and the line says so."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_c_amd.multi_gpu import FramePartition, gather_tiles
+    if world > 1:
+        dist.init_process_group("gloo")
+    part = FramePartition(args.width or 1920, args.height or 1080, world)
+    tiles = torch.full((part.max_local, 1024 * 3), rank, dtype=torch.uint8)
+    t0 = time.perf_counter()
+    got = gather_tiles(tiles, world, rank) if world > 1 else tiles[None]
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = rank != 0 or all(int(got[r][0, 0]) == r for r in range(world))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise RuntimeError("dry run: gathered tiles are not rank-major")
+    if rank == 0:
+        return {"metric": "Mray/s", "value": None, "unit": "Mray/s", "n_gpus": world, "steps": 0, "warmup": 0,
+                "dry_run": True, "chunks_per_rank": [part.n_local(r) for r in range(world)]}
+    return None
+
+
 def main():
     args = parse_args()
+    # Environment of the HIP / RCCL runtimes is fixed BEFORE anything imports torch or touches the GPU: the host
+    # driver of this pool only supports dmabuf IPC, and the runtime reads the variable once at initialisation.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)            # does not return
     # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL prints its
     # version block there at communicator creation) are sent to stderr for the whole run.
     json_fd = os.dup(1)
@@ -134,12 +267,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs a torch.distributed launch "
-                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ...)", file=sys.stderr)
-            sys.exit(2)
-        args.gpus = world
+    args.gpus = world
+
+    if args.dry_run:
+        out = dry_run(args, world, rank)
+        if out is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
 
     import numpy as np
     import torch
@@ -161,13 +295,12 @@ def main():
     force_dist = world == 1 and os.environ.get("RT_BENCH_FORCE_DIST") == "1"     # rehearsal: RCCL path with one rank
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_dist:
         import torch.distributed as dist_
         dist = dist_
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -201,7 +334,6 @@ def main():
     frame_no = [0]
     tiles = torch.zeros((max_local, 1024 * 3), dtype=torch.uint8, device=dev)
     multi = world > 1 or force_dist
-    all_tiles = torch.zeros((world, max_local, 1024 * 3), dtype=torch.uint8, device=dev) if multi else None
     params = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, rank, world, args.slab, 0)
 
     def step():
@@ -220,12 +352,14 @@ def main():
         else:
             if rt.lib.rt_resolve(C.byref(params), accum.data_ptr(), tiles.data_ptr(), None, None, stream) != 0:
                 raise RuntimeError(rt.last_error())
-            # framebuffer tiles of every rank -> every rank (RCCL all-gather over xGMI, 6 MB in total)
+            # framebuffer tiles of every rank -> rank 0 (ONE gather: grouped send / recv over xGMI, every peer on its
+            # own link into rank 0; 6 MB in total at 1080p)
             if backend == "nccl":
-                gather_tiles(tiles, all_tiles)
+                all_tiles = gather_tiles(tiles, world, rank)
             else:
-                host_all = gather_tiles(tiles.cpu(), torch.zeros(all_tiles.shape, dtype=torch.uint8))
-                all_tiles.copy_(host_all)
+                all_tiles = gather_tiles(tiles.cpu(), world, rank)
+                if rank == 0:
+                    all_tiles = all_tiles.to(dev)
             if rank == 0:
                 if rt.lib.rt_untile(w, h, world, all_tiles.data_ptr(), image.data_ptr(), stream) != 0:
                     raise RuntimeError(rt.last_error())
@@ -262,6 +396,8 @@ def main():
                           cnt.textured], dtype=torch.int64, device=dev)
     kms = torch.tensor([last_ms], dtype=torch.float64, device=dev)
     if dist is not None:
+        if backend != "nccl":
+            t, stats, kms = t.cpu(), stats.cpu(), kms.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
@@ -272,15 +408,17 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / max(args.steps, 1)
         rays = tot.rays
-        b_ray = tot.bytes_per_ray()
         mrays = rays / sec_per_step / 1e6
-        # roofline of the dominant kernel (rt_path_kernel): algorithmic scene bytes per ray
-        #  x rays of one launch / that launch's duration; at N > 1 every rank
-        # launches one kernel on its share of the chunks, the slowest rank's time is used.
+        # the dominant kernel (rt_path_kernel): at N > 1 every rank launches one kernel on its share of
+        # the chunks, the slowest rank's time is used.
         rays_per_launch = rays / world
-        achieved = rays_per_launch * b_ray / (last_ms * 1e-3) / 1e9 if last_ms > 0 else None
-        workload = f"{cfg['asset']} {w}x{h}, {s} spp, {b} bounces (BASELINE.json configs[2])"
-        traffic = measured_traffic(workload) if world == 1 else None
+        workload = f"{cfg['asset']} {w}x{h}, {s} spp, {b} bounces"
+        if args.config == "helmet" and (w, h, s, b) == (1920, 1080, 256, 8):
+            workload += " (BASELINE.json configs[2])"
+        elif args.config == "helmet4k" and (w, h, s, b) == (3840, 2160, 1024, 16):
+            workload += " (BASELINE.json configs[4])"
+        prof = measured_profile(workload) if world == 1 else None
+        variant = os.environ.get("RT_KERNEL", "default")
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
@@ -288,8 +426,10 @@ def main():
             "config": {"workload": workload,
                        "scene": "assets/helmet.glb = self-contained models/helmet.gltf; procedural 2048x1024 "
                                 "equirect background (background.png is a missing blob); seed 0x1234ABCD",
-                       "partition": f"32x32 chunks dealt to {world} GPU(s) by the (cx + B cy) mod world lattice, {'RCCL' if backend == 'nccl' else backend} "
-                                    "all-gather of u8 tiles" if world > 1 else "single GPU"},
+                       "bvh": "scene_init (the reference's fixed-capacity split, scene.c:311-414)",
+                       "partition": f"32x32 chunks dealt to {world} GPU(s) by the (cx + B cy) mod world lattice, "
+                                    f"{'RCCL' if backend == 'nccl' else backend} gather of u8 tiles to rank 0"
+                                    if world > 1 else "single GPU"},
             "fps": 1.0 / sec_per_step,
             "msample_per_s": w * h * s / sec_per_step / 1e6,
             "rays_per_frame": rays,
@@ -298,18 +438,8 @@ def main():
             "leaf_visits_per_ray": tot.leaf_visits / max(rays, 1),
             "shades_per_ray": tot.shades / max(rays, 1),
             "kernel_ms": last_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
-                         "valu": traffic[0].get("valu") if traffic else None,
-                         "traffic_source": f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "separate passes; 2 x FETCH_SIZE + WRITE_SIZE, x 1024)" if traffic else None,
-                         "kernel": "rt_path_kernel_sched<16, true> (RT_KERNEL=3 default)", "launches_averaged": int(n_launches.value),
-                         "algorithmic_bytes_per_launch": rays_per_launch * b_ray,
-                         "bytes_per_ray": b_ray,
-                         "note": "achieved = algorithmic scene bytes (192 N + 288 L + 112 H + 48 X + 12 M per ray, "
-                                 "counters from the kernel) / mean launch time; the 60 MB scene is cache "
-                                 "resident, so measured HBM traffic is ~2 % of the algorithmic bytes; what binds the kernel is VALU issue + latency at 4 waves per SIMD (`valu`: PMC counters of the same profile)"},
+            "roofline": roofline_block(tot, rays_per_launch, last_ms, n_launches.value, prof,
+                                       f"rt_path_kernel (RT_KERNEL={variant})"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)

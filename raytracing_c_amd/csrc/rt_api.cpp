@@ -71,6 +71,17 @@ extern "C" void rt_clear_error(void) {
     if (e_ != hipSuccess) { rt_fail("%s failed: %s", #expr, hipGetErrorString(e_)); return nullptr; } \
   } while (0)
 
+// Temporary device buffer that is released on every exit path (HIP_TRY returns early).
+struct DevBuf {
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T> T *as() const { return (T *)p; }
+};
+
 // ---------------------------------------------------------------------------------
 // process state
 
@@ -156,9 +167,8 @@ struct RT_Device_Scene {
   int32_t      depth = 0, last_row_offset = 0, bg_texture = -1, n_nodes = 0;
   int32_t      n_triangles = 0, n_materials = 0, n_textures = 0;
   int64_t      bytes = 0;
-  // fingerprint of the host scene this was built from
-  const void  *fp_nodes = nullptr, *fp_tris = nullptr, *fp_bg = nullptr;
-  int64_t      fp_len = 0, fp_depth = 0;
+  // fingerprint of the host scene this was built from (scene_fingerprint)
+  uint64_t     fp = 0;
   // launch state of this device scene: two device scenes can have launches in flight on two streams at once
   unsigned long long *counters = nullptr;      // RT_N_COUNTERS
   uint32_t           *work_head = nullptr;
@@ -213,7 +223,9 @@ static int texture_index(Image const *img, TexturePool &pool) {
   if (!img) return -1;
   auto it = pool.map.find(img);
   if (it != pool.map.end()) return it->second;
-  if (img->components < 3 || img->width <= 0 || img->height <= 0 || !img->pixels.data || img->stride < img->width) {
+  if (img->pixel_type != PT_u8 || img->components < 3 || img->width <= 0 || img->height <= 0 || !img->pixels.data ||
+      img->stride < img->width ||
+      img->pixels.len < (isize)img->stride * img->height * img->components) {     // the upload reads exactly that many bytes
     return -2;
   }
   RT_DTexture t;
@@ -242,8 +254,9 @@ static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t
     if (raw > max_raw) max_raw = raw;
   }
   if (max_raw == 0) return 0;
-  uint8_t *stage = nullptr;
-  HIP_TRY(hipMalloc((void **)&stage, max_raw));
+  DevBuf stage_buf;
+  HIP_TRY(stage_buf.alloc(max_raw));
+  uint8_t *stage = stage_buf.as<uint8_t>();
   int rc = 0;
   for (size_t k = 0; k < pool.sources.size() && rc == 0; k++) {
     const Image *img = pool.sources[k];
@@ -253,9 +266,96 @@ static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t
                                              *d_texels + pool.descs[k].offset, nullptr);
     if (rc == 0) rc = (int)hipDeviceSynchronize();        // the staging buffer is reused by the next texture
   }
-  (void)hipFree(stage);
   if (rc != 0) return rt_fail("texture upload failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
+}
+
+// ---- content stamp of a host Scene -------------------------------------------------------------------------
+// render_thread_proc / render / lightmap_bake keep one device copy per Scene* and must notice when the host
+// scene changed underneath it -- the reference reads the live Scene every frame.  The stamp covers, in full:
+// the BVH nodes, the whole triangle block (coordinates + AoS records incl. shader pointers), every distinct
+// PBR_Shader_Data record, and the descriptor (pointer, size, layout) of every Image a material or the background
+// references; of the texel data of images above 64 KB it covers every 61st 8-byte word (50 MB of textures would
+// cost 6 ms per frame in full), which catches a reloaded or regenerated image but not a single edited texel: after such an edit the
+// host calls rt_scene_invalidate().  ~5 MB at ~10 GB/s: 0.5 ms per frame for the helmet.
+static inline uint64_t mix64(uint64_t h, uint64_t v) {
+  h ^= v;
+  h *= 0x9E3779B97F4A7C15ull;
+  return h ^ (h >> 29);
+}
+
+static uint64_t hash_bytes(uint64_t seed, const void *data, size_t n, size_t stride_words = 1) {
+  const unsigned char *b = (const unsigned char *)data;
+  uint64_t h0 = seed ^ 0x243F6A8885A308D3ull, h1 = seed ^ 0x13198A2E03707344ull;
+  uint64_t h2 = seed ^ 0xA4093822299F31D0ull, h3 = seed ^ 0x082EFA98EC4E6C89ull;
+  size_t words = n / 8, i = 0;
+  const size_t step = 4 * stride_words;
+  for (; i + step <= words; i += step) {         // four independent chains: the multiplies pipeline
+    uint64_t w0, w1, w2, w3;
+    memcpy(&w0, b + 8 * i, 8);
+    memcpy(&w1, b + 8 * (i + stride_words), 8);
+    memcpy(&w2, b + 8 * (i + 2 * stride_words), 8);
+    memcpy(&w3, b + 8 * (i + 3 * stride_words), 8);
+    h0 = mix64(h0, w0); h1 = mix64(h1, w1); h2 = mix64(h2, w2); h3 = mix64(h3, w3);
+  }
+  uint64_t h = mix64(mix64(mix64(h0, h1), h2), h3);
+  for (; i < words; i += stride_words) { uint64_t w; memcpy(&w, b + 8 * i, 8); h = mix64(h, w); }
+  if (stride_words == 1)
+    for (size_t k = words * 8; k < n; k++) h = mix64(h, b[k]);
+  return mix64(h, (uint64_t)n);
+}
+
+static uint64_t hash_image(uint64_t h, Image const *img) {
+  if (!img) return mix64(h, 0x1234u);
+  int64_t desc[6] = {(int64_t)img->components, (int64_t)img->pixel_type, (int64_t)img->width, (int64_t)img->stride,
+                     (int64_t)img->height, (int64_t)(uintptr_t)img->pixels.data};
+  h = hash_bytes(h, desc, sizeof desc);
+  if (img->pixels.data && img->pixel_type == PT_u8 && img->width > 0 && img->height > 0 && img->stride >= img->width &&
+      img->components > 0) {
+    size_t n = (size_t)img->stride * img->height * img->components;
+    if (img->pixels.len >= (isize)n) h = hash_bytes(h, img->pixels.data, n, n > 65536 ? 61 : 1);    // small images in full
+  }
+  return h;
+}
+
+static uint64_t scene_fingerprint(Scene const *scene) {
+  const Triangles &T = scene->triangles;
+  uint64_t h = 0x452821E638D01377ull;
+  int64_t dims[5] = {(int64_t)scene->bvh.depth, (int64_t)scene->bvh.last_row_offset, (int64_t)scene->bvh.nodes.len,
+                     (int64_t)T.len, (int64_t)(uintptr_t)scene->background.proc};
+  h = hash_bytes(h, dims, sizeof dims);
+  if (scene->bvh.nodes.data && scene->bvh.nodes.len > 0)
+    h = hash_bytes(h, scene->bvh.nodes.data, (size_t)scene->bvh.nodes.len * sizeof(BVH_Node));
+  if (T.len > 0 && T.x[0] && T.aos) {
+    for (int k = 0; k < 3; k++) {                // the nine coordinate arrays (one block in scene_init, but not required to be)
+      h = hash_bytes(h, T.x[k], (size_t)T.len * 4);
+      h = hash_bytes(h, T.y[k], (size_t)T.len * 4);
+      h = hash_bytes(h, T.z[k], (size_t)T.len * 4);
+    }
+    h = hash_bytes(h, T.aos, (size_t)T.len * sizeof(Triangle_AOS));
+    const void *last = nullptr;                  // distinct material records, in first-use order
+    std::vector<const void *> seen;
+    for (int i = 0; i < T.len; i++) {
+      const Shader &sh = T.aos[i].shader;
+      if (!sh.data || sh.data == last) continue;
+      last = sh.data;
+      bool dup = false;
+      for (const void *q : seen) if (q == sh.data) { dup = true; break; }
+      if (dup) continue;
+      seen.push_back(sh.data);
+      if (sh.proc == disney_shader_proc || sh.proc == debug_shader_proc) {
+        const PBR_Shader_Data *m = (const PBR_Shader_Data *)sh.data;
+        h = hash_bytes(h, m, sizeof *m);
+        h = hash_image(h, m->texture_albedo);
+        h = hash_image(h, m->texture_normal);
+        h = hash_image(h, m->texture_metal_roughness);
+        h = hash_image(h, m->texture_emission);
+      }
+      if (seen.size() > 4096) break;             // pathological material counts: the pointers are in the AoS hash anyway
+    }
+  }
+  if (scene->background.proc == (Background_Proc)sample_background) h = hash_image(h, (Image const *)scene->background.data);
+  return h;
 }
 
 static float int_bits(int32_t i) {
@@ -325,7 +425,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
         int tm = texture_index(d->texture_metal_roughness, pool);
         int te = texture_index(d->texture_emission, pool);
         if (ta == -2 || tn == -2 || tm == -2 || te == -2) {
-          rt_fail("rt_scene_upload: material of triangle %d references an unusable Image (need u8, >=3 components)", i);
+          rt_fail("rt_scene_upload: material of triangle %d references an unusable Image (need PT_u8, >= 3 components, pixels.len >= stride*height*components)", i);
           return nullptr;
         }
         mat = (int)(mats.size() / 20);
@@ -377,7 +477,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   }
 
   int bg = texture_index((Image const *)scene->background.data, pool);
-  if (bg < 0) { rt_fail("rt_scene_upload: background Image is unusable (need u8, >=3 components)"); return nullptr; }
+  if (bg < 0) { rt_fail("rt_scene_upload: background Image is unusable (need PT_u8, >= 3 components, pixels.len >= stride*height*components)"); return nullptr; }
 
   RT_Device_Scene *d = new RT_Device_Scene();
   if (hipMalloc((void **)&d->counters, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
@@ -399,11 +499,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   d->n_triangles = n;
   d->n_materials = (int32_t)(mats.size() / 20);
   d->n_textures = (int32_t)pool.descs.size();
-  d->fp_nodes = scene->bvh.nodes.data;
-  d->fp_tris = T.x[0];
-  d->fp_bg = scene->background.data;
-  d->fp_len = T.len;
-  d->fp_depth = scene->bvh.depth;
+  d->fp = scene_fingerprint(scene);
   return d;
 }
 
@@ -441,14 +537,12 @@ extern "C" i64 rt_scene_device_bytes(RT_Device_Scene const *dscene) { return dsc
 static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d);
 
 static RT_Device_Scene *cached_scene_locked(Scene const *scene) {
+  if (!scene) { rt_fail("render: scene is NULL"); return nullptr; }
   auto it = g_scene_cache.find(scene);
   if (it != g_scene_cache.end()) {
     RT_Device_Scene *d = it->second;
-    if (d->fp_nodes == scene->bvh.nodes.data && d->fp_tris == scene->triangles.x[0] &&
-        d->fp_bg == scene->background.data && d->fp_len == scene->triangles.len && d->fp_depth == scene->bvh.depth) {
-      return d;
-    }
-    free_device_scene(d);
+    if (d->fp == scene_fingerprint(scene)) return d;
+    free_device_scene(d);                        // the host scene changed since the upload
     g_scene_cache.erase(it);
   }
   RT_Device_Scene *d = upload_scene_locked(scene);
@@ -749,6 +843,7 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     if (!g_ws.wave_times) HIP_TRY(hipMalloc(&g_ws.wave_times, (size_t)65536 * 3 * 8));
     HIP_TRY(hipMemsetAsync(g_ws.wave_times, 0, (size_t)65536 * 3 * 8, stream));
     K.wave_times = g_ws.wave_times;
+    if (n_waves > 65536) n_waves = 65536;          // the diagnostic buffer holds that many waves
     g_ws.wave_times_n = n_waves;
   }
 
@@ -1012,21 +1107,19 @@ static int lightmap_bake_locked(Image const *lightmap, Scene const *scene, isize
     }
   size_t pb = (size_t)lightmap->stride * lightmap->height * lightmap->components;
   size_t ob = (size_t)lightmap->width * lightmap->height * sizeof(int);
-  float *dv = nullptr;
-  int *dow = nullptr;
-  uint8_t *dp = nullptr;
-  HIP_TRY(hipMalloc(&dv, verts.size() * sizeof(float)));
-  HIP_TRY(hipMalloc(&dow, ob));
-  HIP_TRY(hipMalloc(&dp, pb));
+  DevBuf b_verts, b_owner, b_pixels;
+  HIP_TRY(b_verts.alloc(verts.size() * sizeof(float)));
+  HIP_TRY(b_owner.alloc(ob));
+  HIP_TRY(b_pixels.alloc(pb));
+  float *dv = b_verts.as<float>();
+  int *dow = b_owner.as<int>();
+  uint8_t *dp = b_pixels.as<uint8_t>();
   HIP_TRY(hipMemcpy(dv, verts.data(), verts.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(dow, 0xFF, ob));                                        // owner = -1
   HIP_TRY(hipMemcpy(dp, lightmap->pixels.data, pb, hipMemcpyHostToDevice));   // untouched texels keep their value
   int rc = rt_launch_lightmap(&K, dv, T.len, (int)lightmap->width, (int)lightmap->height, (int)lightmap->stride,
                               (int)lightmap->components, (int)samples, dow, dp, nullptr);
   if (rc == 0) rc = (int)hipMemcpy(lightmap->pixels.data, dp, pb, hipMemcpyDeviceToHost);
-  (void)hipFree(dv);
-  (void)hipFree(dow);
-  (void)hipFree(dp);
   if (rc != 0) return rt_fail("lightmap_bake failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
@@ -1061,16 +1154,15 @@ static int denoise_host(Image const *src, Image const *dst) {
     return rt_fail("denoise_image: bad layout");
   size_t sb = (size_t)src->stride * src->height * src->components;
   size_t db = (size_t)dst->stride * dst->height * dst->components;
-  uint8_t *ds = nullptr, *dd = nullptr;
-  HIP_TRY(hipMalloc(&ds, sb));
-  HIP_TRY(hipMalloc(&dd, db));
+  DevBuf b_src, b_dst;
+  HIP_TRY(b_src.alloc(sb));
+  HIP_TRY(b_dst.alloc(db));
+  uint8_t *ds = b_src.as<uint8_t>(), *dd = b_dst.as<uint8_t>();
   HIP_TRY(hipMemcpy(ds, src->pixels.data, sb, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dd, dst->pixels.data, db, hipMemcpyHostToDevice));     // components beyond 3 keep their values
   int rc = rt_launch_denoise((int)src->width, (int)src->height, (int)src->stride, (int)src->components,
                              (int)dst->stride, (int)dst->components, ds, dd, nullptr);
   if (rc == 0) rc = (int)hipMemcpy(dst->pixels.data, dd, db, hipMemcpyDeviceToHost);
-  (void)hipFree(ds);
-  (void)hipFree(dd);
   if (rc != 0) return rt_fail("denoise_image failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
@@ -1087,20 +1179,19 @@ extern "C" int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out)
   std::lock_guard<std::mutex> lock(g_mutex);
   if (ensure_device() != 0) return -1;
   if (n <= 0 || !x || !out) return rt_fail("rt_test_math: bad arguments");
-  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  DevBuf bx, by, bout;
   size_t bytes = (size_t)n * sizeof(float);
-  HIP_TRY(hipMalloc(&dx, bytes));
-  HIP_TRY(hipMalloc(&dout, bytes));
+  HIP_TRY(bx.alloc(bytes));
+  HIP_TRY(bout.alloc(bytes));
+  float *dx = bx.as<float>(), *dy = nullptr, *dout = bout.as<float>();
   HIP_TRY(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
   if (y) {
-    HIP_TRY(hipMalloc(&dy, bytes));
+    HIP_TRY(by.alloc(bytes));
+    dy = by.as<float>();
     HIP_TRY(hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
   }
   int rc = rt_launch_test_math(op, n, dx, dy, dout, nullptr);
   if (rc == 0) rc = (int)hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
-  (void)hipFree(dx);
-  (void)hipFree(dy);
-  (void)hipFree(dout);
   if (rc != 0) return rt_fail("rt_test_math failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
@@ -1125,21 +1216,18 @@ extern "C" int rt_test_trace(RT_Device_Scene *d, i32 n, f32 const *rays, f32 *ou
   if (!d || n <= 0 || !rays || !out_t || !out_tri || !out_uv) return rt_fail("rt_test_trace: bad arguments");
   RT_KParams K;
   scene_only_kparams(&K, d);
-  float *dr = nullptr, *dt = nullptr, *duv = nullptr;
-  int   *dtri = nullptr;
-  HIP_TRY(hipMalloc(&dr, (size_t)n * 24));
-  HIP_TRY(hipMalloc(&dt, (size_t)n * 4));
-  HIP_TRY(hipMalloc(&dtri, (size_t)n * 4));
-  HIP_TRY(hipMalloc(&duv, (size_t)n * 8));
+  DevBuf br, bt, btri, buv;
+  HIP_TRY(br.alloc((size_t)n * 24));
+  HIP_TRY(bt.alloc((size_t)n * 4));
+  HIP_TRY(btri.alloc((size_t)n * 4));
+  HIP_TRY(buv.alloc((size_t)n * 8));
+  float *dr = br.as<float>(), *dt = bt.as<float>(), *duv = buv.as<float>();
+  int   *dtri = btri.as<int>();
   HIP_TRY(hipMemcpy(dr, rays, (size_t)n * 24, hipMemcpyHostToDevice));
   int rc = rt_launch_test_trace(&K, n, dr, dt, dtri, duv, nullptr);
   if (rc == 0) rc = (int)hipMemcpy(out_t, dt, (size_t)n * 4, hipMemcpyDeviceToHost);
   if (rc == 0) rc = (int)hipMemcpy(out_tri, dtri, (size_t)n * 4, hipMemcpyDeviceToHost);
   if (rc == 0) rc = (int)hipMemcpy(out_uv, duv, (size_t)n * 8, hipMemcpyDeviceToHost);
-  (void)hipFree(dr);
-  (void)hipFree(dt);
-  (void)hipFree(dtri);
-  (void)hipFree(duv);
   if (rc != 0) return rt_fail("rt_test_trace failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
@@ -1152,14 +1240,13 @@ extern "C" int rt_test_texture(RT_Device_Scene *d, i32 tex, i32 n, f32 const *uv
   if (tex >= d->n_textures) return rt_fail("rt_test_texture: texture %d of %d", tex, d->n_textures);
   RT_KParams K;
   scene_only_kparams(&K, d);
-  float *duv = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(&duv, (size_t)n * 8));
-  HIP_TRY(hipMalloc(&dout, (size_t)n * 12));
+  DevBuf buv, bout;
+  HIP_TRY(buv.alloc((size_t)n * 8));
+  HIP_TRY(bout.alloc((size_t)n * 12));
+  float *duv = buv.as<float>(), *dout = bout.as<float>();
   HIP_TRY(hipMemcpy(duv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
   int rc = rt_launch_test_texture(&K, tex, n, duv, dout, nullptr);
   if (rc == 0) rc = (int)hipMemcpy(out_rgb, dout, (size_t)n * 12, hipMemcpyDeviceToHost);
-  (void)hipFree(duv);
-  (void)hipFree(dout);
   if (rc != 0) return rt_fail("rt_test_texture failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }

@@ -17,6 +17,38 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* The device layer (rt_api.cpp) keeps an HBM copy per Scene*: building into or freeing a Scene drops it.  Weak, so
+ * that this file also links on its own (host-only tools, the sanitizer build of tests/c/). */
+extern void rt_scene_invalidate(Scene const *scene) __attribute__((weak));
+
+/* Blocks handed out by the DEFAULT allocator (Allocator.proc == NULL): rt_scene_free() releases exactly these.
+ * Memory from a caller's Allocator, and a scene that aliases a file buffer (scene_load_bytes), is the caller's. */
+static pthread_mutex_t g_owned_mutex = PTHREAD_MUTEX_INITIALIZER;
+static rawptr         *g_owned = NULL;
+static isize           g_owned_len = 0, g_owned_cap = 0;
+
+static void owned_add(rawptr p) {
+  pthread_mutex_lock(&g_owned_mutex);
+  if (g_owned_len == g_owned_cap) {
+    isize cap = g_owned_cap ? g_owned_cap * 2 : 16;
+    rawptr *grown = (rawptr *)realloc(g_owned, (size_t)cap * sizeof *grown);
+    if (grown) { g_owned = grown; g_owned_cap = cap; }
+  }
+  if (g_owned_len < g_owned_cap) g_owned[g_owned_len++] = p;     /* (on realloc failure the block is simply never freed) */
+  pthread_mutex_unlock(&g_owned_mutex);
+}
+
+static bool owned_take(rawptr p) {
+  bool found = false;
+  pthread_mutex_lock(&g_owned_mutex);
+  for (isize i = 0; i < g_owned_len; i++) {
+    if (g_owned[i] == p) { g_owned[i] = g_owned[--g_owned_len]; found = true; break; }
+  }
+  if (g_owned_len == 0) { free(g_owned); g_owned = NULL; g_owned_cap = 0; }
+  pthread_mutex_unlock(&g_owned_mutex);
+  return found;
+}
+
 static rawptr rt_alloc_zeroed(Allocator a, isize size, isize align) {
   if (size <= 0) size = align;
   rawptr p;
@@ -25,6 +57,7 @@ static rawptr rt_alloc_zeroed(Allocator a, isize size, isize align) {
   } else {
     isize rounded = (size + align - 1) / align * align;
     p = aligned_alloc((size_t)align, (size_t)rounded);
+    if (p) owned_add(p);
   }
   if (p) memset(p, 0, (size_t)size);
   return p;
@@ -275,13 +308,22 @@ static void *build_job_run(void *arg) {
 /* scene.c:416-426.  Sorts a private copy of the input (the reference sorts the
  * caller's slice in place). */
 void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
+  if (rt_scene_invalidate) rt_scene_invalidate(scene);      /* a device copy of what this Scene held before is stale */
   isize depth      = bvh_required_depth(src.len);
   isize n_internal = bvh_n_internal_nodes(depth);
   scene->bvh.depth           = depth;
   scene->bvh.last_row_offset = n_internal;
   scene->bvh.nodes.len       = n_internal;
   scene->bvh.nodes.data      = (BVH_Node *)rt_alloc_zeroed(allocator, n_internal * (isize)sizeof(BVH_Node), 64);
-  if (!triangles_init(&scene->triangles, bvh_n_leaf_nodes(depth) * RT_BVH_WIDTH, allocator)) return;
+  memset(&scene->triangles, 0, sizeof scene->triangles);
+  if (!scene->bvh.nodes.data) {          /* allocation failed: an empty scene (len 0), which the upload refuses */
+    scene->bvh.nodes.len = 0;
+    return;
+  }
+  if (!triangles_init(&scene->triangles, bvh_n_leaf_nodes(depth) * RT_BVH_WIDTH, allocator)) {
+    memset(&scene->triangles, 0, sizeof scene->triangles);
+    return;
+  }
   if (src.len <= 0) return;
 
   isize n = src.len;
@@ -297,10 +339,13 @@ void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
   free(work); free(sb.keys); free(sb.tmp); free(sb.scratch);
 }
 
+/* Releases what scene_init() allocated with the DEFAULT allocator and drops the device copy.  Blocks that came from
+ * a caller's Allocator, or that alias a file buffer (scene_load_bytes), are not touched: they are the caller's. */
 void rt_scene_free(Scene *scene) {
   if (!scene) return;
-  free(scene->bvh.nodes.data);
-  free(scene->triangles.x[0]);
+  if (rt_scene_invalidate) rt_scene_invalidate(scene);
+  if (scene->bvh.nodes.data && owned_take(scene->bvh.nodes.data)) free(scene->bvh.nodes.data);
+  if (scene->triangles.x[0] && owned_take(scene->triangles.x[0])) free(scene->triangles.x[0]);
   scene->bvh.nodes.data = NULL;
   scene->bvh.nodes.len  = 0;
   memset(&scene->triangles, 0, sizeof scene->triangles);

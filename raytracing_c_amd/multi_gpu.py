@@ -4,7 +4,7 @@ The reference work-steals 32x32 chunks between threads (raytracer.c:601-627); he
 owned by rank (cx + B * cy) % world (a lattice that spreads every chunk column and row over all ranks:
 include/rt_hip.h, rt_chunk_owner), every
 rank renders its chunks with rt_render_accumulate / rt_resolve into a compact
-[max_local][32*32*3] u8 tile buffer, ONE RCCL all-gather moves the tiles over xGMI (6.2 MB for
+[max_local][32*32*3] u8 tile buffer, ONE RCCL gather moves the tiles over xGMI to rank 0 (6.2 MB for
 1080p in total) and rt_untile scatters them into the row-major image.  Per-path seeds depend
 only on (pixel, sample), so the image does not depend on `world`.
 
@@ -79,9 +79,27 @@ def untile(all_tiles, width, height, world):
     return image
 
 
-def gather_tiles(tiles, all_tiles):
-    """tiles: this rank's (max_local, 3072) u8 tensor; all_tiles: (world, max_local, 3072) tensor on the
-    same device.  One all-gather (RCCL on GPUs, gloo in the CPU tests)."""
+_gather_buffers = {}
+
+
+def gather_tiles(tiles, world, rank, dst=0):
+    """tiles: this rank's (max_local, 3072) u8 tensor.  ONE gather to rank `dst`: returns the
+    (world, max_local, 3072) rank-major tensor there (on the device of `tiles`), None on the other ranks.
+
+    With the nccl backend torch issues this as one group of ncclSend / ncclRecv: on the fully connected xGMI
+    topology every peer has its own link into rank 0, so the exchange costs one tile buffer per link (0.78 MB at
+    1080p u8) instead of the world-1 ring steps of an all-gather that would also deliver the frame to ranks
+    that never use it.  gloo in the CPU tests."""
+    import torch
     import torch.distributed as dist
-    dist.all_gather_into_tensor(all_tiles.view(-1), tiles.view(-1))
-    return all_tiles
+    if rank != dst:
+        dist.gather(tiles, None, dst=dst)
+        return None
+    key = (tiles.device, tuple(tiles.shape), world)
+    buf = _gather_buffers.get(key)
+    if buf is None:
+        buf = torch.zeros((world,) + tuple(tiles.shape), dtype=tiles.dtype, device=tiles.device)
+        _gather_buffers.clear()
+        _gather_buffers[key] = buf
+    dist.gather(tiles, list(buf.unbind(0)), dst=dst)
+    return buf

@@ -1,0 +1,39 @@
+"""bench.py started WITHOUT a launcher must start its own ranks (`python bench.py --gpus N`, the form the driver uses):
+the parent spawns `python -m torch.distributed.run ...` as a child before it imports torch or touches a GPU, relays
+rank 0's single JSON line and exits with the children's status.  `--dry-run` keeps the children off the GPU (gloo
+rendezvous, partition tables, the tile gather), so the whole launcher branch runs on a CPU-only machine."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=300, env=e, cwd=ROOT)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_bench_starts_its_own_ranks(n):
+    r = _run("--gpus", str(n), "--dry-run", "--width", "200", "--height", "120")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # exactly ONE line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["dry_run"] is True
+    assert sum(out["chunks_per_rank"]) == 7 * 4 and len(out["chunks_per_rank"]) == n
+
+
+def test_bench_launcher_relays_failure_status():
+    # the children fail (an option the ranks reject): the parent must not print a result line and must not exit 0
+    r = _run("--gpus", "2", "--dry-run", "--config-does-not-exist")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

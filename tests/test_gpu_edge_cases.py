@@ -97,3 +97,93 @@ def test_second_frame_on_the_same_scene_reuses_the_device_copy(rt, oracle):
     b = rt.render_context(hs, 64, 40, 2, 4)["image"]
     assert np.array_equal(b, want)
     assert not np.array_equal(a, b)
+
+
+def _textured_quad():
+    """two triangles with one textured material (4x4 albedo), looked at head on"""
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.scene import Material, build_scene
+    pos = np.array([[[-1, -1, 0], [1, -1, 0], [1, 1, 0]], [[-1, -1, 0], [1, 1, 0], [-1, 1, 0]]], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (2, 3, 1))
+    uv = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32)
+    tex = (np.arange(4 * 4 * 3, dtype=np.uint32) * 5 % 256).astype(np.uint8).reshape(4, 4, 3)
+    cam = np.eye(4, dtype=np.float32)
+    cam[2, 3] = 2.5
+    mats = [Material(base_color=(0.9, 0.8, 0.7), roughness=0.6, texture_albedo=0)]
+    return build_scene(pos, nrm, uv, np.zeros(2, np.int32), mats, [tex], cam, 1.0, procedural_background(64, 32))
+
+
+def test_in_place_scene_edits_are_seen_by_the_next_frame(rt, oracle):
+    """The reference reads the live Scene every frame (raytracer.c:596-720 holds no copy).  render_thread_proc keeps a
+    device copy per Scene*, so it must notice host-side edits: a material colour, a vertex, a texture swapped for
+    another Image are all covered by the content stamp; a single edited texel needs rt_scene_invalidate()."""
+    from tests import _oracle
+    hs = _textured_quad()
+    w, h, s, b = 48, 32, 4, 3
+    first = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(first, _oracle.render(hs, w, h, s, b)["image"])
+
+    hs.materials[0].base_color.x = 0.1                      # 1. material record edited in place
+    got = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(got, _oracle.render(hs, w, h, s, b)["image"])
+    assert not np.array_equal(got, first)
+
+    hs.soa_array()[6:9, :2] -= 0.25                         # 2. geometry edited in place: both triangles move back (z)
+    got2 = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(got2, _oracle.render(hs, w, h, s, b)["image"])
+    assert not np.array_equal(got2, got)
+
+    hs._image_arrays[0][...] = 255 - hs._image_arrays[0]   # 3. every texel rewritten (an image reloaded in place)
+    got3 = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(got3, _oracle.render(hs, w, h, s, b)["image"])
+    assert not np.array_equal(got3, got2)
+
+    hs._image_arrays[0][1, 2, 0] ^= 0x80                    # 4. ONE texel: outside the stamp's sample -> explicit invalidate
+    rt.lib.rt_scene_invalidate(C.byref(hs.scene))
+    got4 = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(got4, _oracle.render(hs, w, h, s, b)["image"])
+
+
+def test_scene_rebuilt_at_the_same_address_is_not_served_from_the_cache(rt, oracle):
+    """rt_scene_free() + scene_init() of a same-size scene into the same Scene struct very likely gets the same malloc
+    blocks back; pointer identity cannot tell the two scenes apart.  scene_init / rt_scene_free drop the
+    device copy, and the content stamp differs anyway."""
+    from raytracing_c_amd import ctypes_abi as abi
+    from tests import _oracle
+    hs = _textured_quad()
+    w, h, s, b = 40, 24, 2, 3
+    a = rt.render_context(hs, w, h, s, b)["image"]
+    old_nodes, old_tris = hs.scene.bvh.nodes.data, C.cast(hs.scene.triangles.x[0], C.c_void_p).value
+    # rebuild IN PLACE with different geometry (the quad shrunk to half its size)
+    tri = np.zeros(2, abi.TRIANGLE_DTYPE)
+    pos = np.array([[[-.5, -.5, 0], [.5, -.5, 0], [.5, .5, 0]], [[-.5, -.5, 0], [.5, .5, 0], [-.5, .5, 0]]], np.float32)
+    tri["positions"] = pos
+    tri["normals"] = np.tile(np.array([0, 0, 1], np.float32), (2, 3, 1))
+    tri["tex_coords"] = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32)
+    tri["shader_data"] = C.addressof(hs.materials)
+    tri["shader_proc"] = rt.native.symbol_address("disney_shader_proc")
+    rt.lib.rt_scene_free(C.byref(hs.scene))
+    rt.lib.scene_init(C.byref(hs.scene), abi.Triangle_Slice(tri.ctypes.data, 2), abi.Allocator(None, None))
+    same_blocks = (hs.scene.bvh.nodes.data == old_nodes and C.cast(hs.scene.triangles.x[0], C.c_void_p).value == old_tris)
+    got = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(got, _oracle.render(hs, w, h, s, b)["image"]), f"stale device scene (same blocks: {same_blocks})"
+    assert not np.array_equal(got, a)
+
+
+def test_non_u8_or_short_texture_is_refused(rt):
+    """texture_index(): an Image that is not PT_u8, or whose pixels slice is shorter than stride*height*components, must be
+    refused loudly instead of being uploaded as raw bytes / over-read."""
+    hs = _textured_quad()
+    hs.images[0].pixel_type = 1
+    rt.lib.rt_clear_error()
+    assert not rt.lib.rt_scene_upload(C.byref(hs.scene))
+    assert "unusable Image" in rt.last_error()
+    hs.images[0].pixel_type = 0
+    hs.images[0].pixels.len = 4 * 4 * 3 - 1
+    rt.lib.rt_clear_error()
+    assert not rt.lib.rt_scene_upload(C.byref(hs.scene))
+    assert "unusable Image" in rt.last_error()
+    hs.images[0].pixels.len = 4 * 4 * 3
+    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    assert d, rt.last_error()
+    rt.lib.rt_scene_release(d)

@@ -171,6 +171,37 @@ def test_config5_4k_window(rt, helmet):
     assert np.array_equal(acc[y0:y1, x0:x1], want[y0:y1, x0:x1])
 
 
+def test_config5_entire_frame_full_spp(rt, helmet):
+    """BASELINE.json configs[4] IN FULL on one GPU -- helmet 3840x2160, 1024 spp, 16 bounces: 8 493 465 600 paths in one
+    launch (render_thread_proc's loop of raytracer.c:596-720 over the whole frame, about 0.75 s).  Checked through
+    size-independent properties: exact path count; two oracle windows at the full 1024 spp, bit-exact (the oracle renders
+    only the window, with the full frame's size and spp, so seeds, jitter and rays are the full frame's); the sum of 16
+    sample ranges of 64 equals the single launch on every one of the 24.9 M radiance sums; rays/paths/backgrounds
+    consistent."""
+    from tests import _oracle
+    torch = helmet.torch
+    w, h, s, b = 3840, 2160, 1024, 16
+    full_t = helmet.accumulate(w, h, s, b)
+    c = rt.render.get_counters()
+    assert c.paths == w * h * s == 8493465600
+    assert c.rays >= c.paths and c.backgrounds <= c.paths and c.textured == c.shades
+    assert c.rays == c.paths + (c.rays - c.paths) and c.node_visits >= c.rays          # every ray enters the root
+    rays_full = c.rays
+    full = _np(full_t)
+    for (x0, y0, x1, y1) in [(1700, 900, 1712, 908), (2300, 1300, 2308, 1308)]:        # visor / lower shell: deep paths
+        want = _oracle.render(helmet.hs, w, h, s, b, window=(x0, y0, x1, y1), n_threads=_host_threads())["accum"]
+        assert np.array_equal(full[y0:y1, x0:x1], want[y0:y1, x0:x1]), (x0, y0)
+    del full
+    # 16 launches of 64 samples each into one buffer == the single launch (integer accumulation is exact)
+    acc = None
+    rays = 0
+    for k in range(16):
+        acc = helmet.accumulate(w, h, s, b, accum=acc, first=64 * k, count=64)
+        rays += rt.render.get_counters().rays
+    assert rays == rays_full
+    assert bool(torch.equal(acc, full_t))
+
+
 def test_config2_quad_full(rt):
     """quad 512x512, 64 spp, 4 bounces (BASELINE.json configs[1], depth-0 BVH): the WHOLE frame bit-exact."""
     from raytracing_c_amd.configs import load_config

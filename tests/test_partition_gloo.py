@@ -1,7 +1,7 @@
 """Multi-process path on CPU: world_size 2 and 3 with gloo.
 
 Each rank owns the chunks rt_chunk_owner() gives it (lattice partition, include/rt_hip.h), fills its compact tile
-buffer, ONE all-gather moves the tiles, untile() rebuilds the frame.  The GPU path runs the same
+buffer, ONE gather moves the tiles to rank 0, untile() rebuilds the frame there.  The GPU path runs the same
 FramePartition / gather_tiles code with RCCL; rt_resolve / rt_untile (HIP) implement the two
 layouts that extract_tiles() / untile() state in numpy (checked on the GPU in test_gpu_parity.py).
 """
@@ -38,10 +38,11 @@ def _worker(rank, world, port, width, height, seed, out_dir):
             x0, y0 = part.chunk_origin(c)
             mine[y0:y0 + 32, x0:x0 + 32] = full[y0:y0 + 32, x0:x0 + 32]
         tiles = torch.from_numpy(extract_tiles(mine, rank, world))
-        all_tiles = torch.zeros((world, part.max_local, 32 * 32 * 3), dtype=torch.uint8)
-        gather_tiles(tiles, all_tiles)
-        image = untile(all_tiles.numpy(), width, height, world)
-        ok = np.array_equal(image, full)
+        all_tiles = gather_tiles(tiles, world, rank)
+        ok = (all_tiles is None) == (rank != 0)
+        if rank == 0:
+            image = untile(all_tiles.numpy(), width, height, world)
+            ok = ok and np.array_equal(image, full)
         # the timing rule of bench.py: MAX over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

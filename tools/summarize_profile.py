@@ -15,11 +15,11 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    lines = [f"# rocprofv3 summary `{tag}` -- bench.py (helmet 1920x1080, 256 spp, 8 bounces, 1 x MI355X)", ""]
+    lines = [f"# rocprofv3 summary `{tag}` -- bench.py {os.environ.get('BENCH_ARGS', '(helmet 1920x1080, 256 spp, 8 bounces)')}, 1 x MI355X", ""]
     stats = sorted(glob.glob(os.path.join(src, f"prof_{tag}_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]
     kernel_avg_ms = None
     if stats:
-        lines += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 9 --warmup 1`", "",
+        lines += [f"## `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps {os.environ.get('STEPS', '9')} --warmup 1 {os.environ.get('BENCH_ARGS', '')}`", "",
                   "| kernel | calls | total ms | average ms | % | min ms | max ms |", "|---|---|---|---|---|---|---|"]
         for r in csv.DictReader(open(stats[0])):
             name = r["Name"].split("(")[0][:60]
@@ -69,8 +69,9 @@ def main(tag):
         lines += [f"HBM-side traffic per launch = (2 x {fetch_kb:.0f} + {write_kb:.0f}) KB = **{hbm/1e9:.2f} GB** "
                   "(FETCH_SIZE doubled per MI355X_MICROARCH.md; it counts L2 fabric requests, Infinity-Cache hits included).", ""]
         if bench:
-            alg = bench["rays_per_frame"] * bench["roofline"]["bytes_per_ray"]
-            lines += [f"Algorithmic scene bytes per launch = {bench['rays_per_frame']} rays x {bench['roofline']['bytes_per_ray']:.1f} B "
+            b_ray = bench["roofline"]["algorithmic"]["bytes_per_ray"]
+            alg = bench["rays_per_frame"] * b_ray
+            lines += [f"Algorithmic scene bytes per launch = {bench['rays_per_frame']} rays x {b_ray:.1f} B "
                       f"= {alg/1e9:.1f} GB -> traffic/algorithmic = {hbm/alg:.4f}: the ~60 MB scene is served by L1/L2/Infinity Cache, "
                       "the kernel is not HBM bound.", ""]
         if "TCC_HIT_sum" in counters:
@@ -89,6 +90,7 @@ def main(tag):
         # VALU issue: a wave64 fp32 instruction occupies its SIMD for 2 cycles (128 fp32 lanes per CU = 4 SIMDs x 32);
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs
         simd_cycles = counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        traffic["gui_active_cycles_per_xcd"] = counters["GRBM_GUI_ACTIVE"] / 8.0
         traffic["valu"] = {"wave_insts": counters["SQ_INSTS_VALU"],
                            "issue_frac": 2.0 * counters["SQ_INSTS_VALU"] / simd_cycles,
                            "active_lane_frac": counters["SQ_THREAD_CYCLES_VALU"] / (64 * counters["SQ_ACTIVE_INST_VALU"])
