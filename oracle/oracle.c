@@ -8,6 +8,7 @@
 #include "oracle.h"
 #include "../include/rt_math.h"
 
+#include <immintrin.h>
 #include <pthread.h>
 #include <stdatomic.h>
 #include <stdlib.h>
@@ -20,6 +21,9 @@
 static _Thread_local u32             random_state;
 static _Thread_local Oracle_Counters tl_counters;
 static _Thread_local f32             tl_bary_u, tl_bary_v;   /* barycentrics of the last accepted hit */
+/* ORACLE_LITERAL (oracle.h): the reference's literal semantics where the default oracle deviates (D1, D2, D6, D8) */
+static _Thread_local bool            tl_literal;
+#define PI_D 3.14159265358979323846      /* codin's PI is not in the reference tree; taken as a double constant */
 
 static inline f32 rand_f32(void) { return rt_rand_f32(&random_state); }
 
@@ -212,6 +216,10 @@ static rt_v3 sample_texture_bilinear(Image const *texture, f32 tx, f32 ty) {
 static rt_v3 sample_background_image(Image const *image, rt_v3 dir) {
   f32 inv_pi     = 1.0f / RT_PI;
   f32 inv_two_pi = 1.0f / (2.0f * RT_PI);
+  if (tl_literal) {                        /* driver.c:96-97 with a double PI: one rounding each */
+    inv_pi     = (f32)(1.0 / PI_D);
+    inv_two_pi = (f32)(1.0 / (2.0 * PI_D));
+  }
   f32 u = 0.5f + rt_atan2f(dir.z, dir.x) * inv_two_pi;
   f32 v = 0.5f - rt_asinf(dir.y) * inv_pi;
   return rt_srgb_to_linear(sample_texture_bilinear(image, u, v));
@@ -219,7 +227,9 @@ static rt_v3 sample_background_image(Image const *image, rt_v3 dir) {
 
 /* driver.c:118-127 */
 static rt_v3 sample_cosine_hemisphere(void) {
-  f32 angle    = rand_f32() * 2.0f * RT_PI;
+  f32 r1       = rand_f32();
+  /* driver.c:119 `rand_f32() * 2 * PI`; literal: the float product times a double PI, rounded once */
+  f32 angle    = tl_literal ? (f32)((double)(r1 * 2.0f) * PI_D) : r1 * 2.0f * RT_PI;
   f32 distance = rt_sqrtf(rand_f32());
   f32 s, c;
   rt_sincosf(angle, &s, &c);
@@ -291,6 +301,8 @@ static f32 distribution_GGX(f32 roughness, f32 NoH) {   /* k == 2 at every call 
 static f32 smith_G(f32 NDotV, f32 alpha2) {
   f32 a = alpha2 * alpha2;
   f32 b = NDotV * NDotV;
+  /* driver.c:220 `(2.0 * NDotV) / (...)`: the double literal makes this a double division (D8) */
+  if (tl_literal) return (f32)((2.0 * (double)NDotV) / (double)(NDotV + rt_sqrtf(a + b - a * b)));
   return (2.0f * NDotV) / (NDotV + rt_sqrtf(a + b - a * b));
 }
 
@@ -308,16 +320,27 @@ static rt_v3 sample_GGX_VNDF(rt_v3 Vv, f32 ax, f32 ay) {
   rt_v3 T2 = rt_v3_cross(Vh, T1);
 
   f32 r   = rt_sqrtf(rand_f32());
-  f32 phi = 2.0f * RT_PI * rand_f32();
+  f32 ru  = rand_f32();
+  /* driver.c:238-246 carry double literals (D8): `2.0 * PI * rand`, `0.5 * (1.0 + Vh.z)`,
+   * `(1.0 - s) * sqrt_f32(1.0 - t1 * t1) + s * t2`, `max(0.0, 1.0 - t1 * t1 - t2 * t2)` are evaluated in double and
+   * rounded to f32 once where the default oracle rounds every step.  The literal form follows C's promotion rules. */
+  f32 phi = tl_literal ? (f32)(2.0 * PI_D * (double)ru) : 2.0f * RT_PI * ru;
   f32 sn, cs;
   rt_sincosf(phi, &sn, &cs);
   f32 t1 = r * cs;
   f32 t2 = r * sn;
-  f32 s  = 0.5f * (1.0f + Vh.z);
-  t2     = (1.0f - s) * rt_sqrtf(1.0f - t1 * t1) + s * t2;
+  f32 s  = 0.5f * (1.0f + Vh.z);           /* the double form gives the same f32: the halving is exact */
+  f32 tail;
+  if (tl_literal) {
+    t2   = (f32)((1.0 - (double)s) * (double)rt_sqrtf((f32)(1.0 - (double)(t1 * t1))) + (double)(s * t2));
+    double rest = 1.0 - (double)(t1 * t1) - (double)(t2 * t2);
+    tail = rt_sqrtf((f32)(rest > 0.0 ? rest : 0.0));
+  } else {
+    t2   = (1.0f - s) * rt_sqrtf(1.0f - t1 * t1) + s * t2;
+    tail = rt_sqrtf(rt_max_ps(0.0f, 1.0f - t1 * t1 - t2 * t2));
+  }
 
-  rt_v3 Nh = rt_v3_add(rt_v3_add(rt_v3_scale(T1, t1), rt_v3_scale(T2, t2)),
-                       rt_v3_scale(Vh, rt_sqrtf(rt_max_ps(0.0f, 1.0f - t1 * t1 - t2 * t2))));
+  rt_v3 Nh = rt_v3_add(rt_v3_add(rt_v3_scale(T1, t1), rt_v3_scale(T2, t2)), rt_v3_scale(Vh, tail));
 
   return rt_v3_normalize(rt_v3_make(ax * Nh.x, ay * Nh.y, rt_max_ps(0.0f, Nh.z)));
 }
@@ -559,6 +582,9 @@ static Ray primary_ray(Camera const *camera, i32 width, i32 height, i32 x, i32 y
   f32 dz = -camera->focal_length;
 
   f32 inv_length = 1.0f / rt_sqrtf(dx * dx + dy * dy + dz * dz);
+  if (tl_literal) {                        /* raytracer.c:663: the ~12-bit hardware estimate, not 1/sqrt (D2) */
+    inv_length = _mm_cvtss_f32(_mm256_castps256_ps128(_mm256_rsqrt_ps(_mm256_set1_ps(dx * dx + dy * dy + dz * dz))));
+  }
 
   f32 const (*m)[4] = camera->view_matrix.rows;
   f32 rx = m[0][0] * dx + m[0][1] * dy + m[0][2] * dz;
@@ -578,7 +604,7 @@ static Ray primary_ray(Camera const *camera, i32 width, i32 height, i32 x, i32 y
 
 static rt_v3 trace_path(Scene const *scene, Oracle_Config const *cfg, i32 width, i32 height,
                         i32 x, i32 y, i32 sample, i32 max_bounces) {
-  random_state = rt_path_seed(cfg->seed, (u32)(x + y * width), (u32)sample);   /* D1 */
+  if (!tl_literal) random_state = rt_path_seed(cfg->seed, (u32)(x + y * width), (u32)sample);   /* D1 */
   tl_counters.paths += 1;
   Ray r = primary_ray(&scene->camera, width, height, x, y, sample);
   return cast_ray(scene, cfg, r, max_bounces);
@@ -610,6 +636,10 @@ typedef struct {
 static void *oracle_worker(void *arg) {
   Oracle_Job *job = (Oracle_Job *)arg;
   memset(&tl_counters, 0, sizeof tl_counters);
+  /* ORACLE_LITERAL: one RNG stream per thread, seeded once and running on across pixels and chunks
+   * (raytracer.c:597 `random_state = time_now()`, with the frame seed in place of the clock) */
+  tl_literal = job->cfg.literal != 0;
+  if (tl_literal) random_state = job->cfg.seed;
 
   i32 width = job->width, height = job->height;
   i32 x0 = job->cfg.x0, y0 = job->cfg.y0, x1 = job->cfg.x1, y1 = job->cfg.y1;
@@ -643,7 +673,7 @@ static void *oracle_worker(void *arg) {
         }
 
         f32 lin[3];
-        if (job->cfg.accum_mode == ORACLE_ACCUM_F32) {
+        if (job->cfg.accum_mode == ORACLE_ACCUM_F32 || tl_literal) {
           color = rt_v3_scale(color, inv_samples);            /* raytracer.c:700 */
           lin[0] = color.x; lin[1] = color.y; lin[2] = color.z;
         } else {
@@ -698,11 +728,13 @@ int oracle_render(Scene const *scene, Image const *image, isize samples, isize m
 
   i32 n = config->n_threads < 1 ? 1 : config->n_threads;
   if (n > 256) n = 256;
+  if (config->literal) n = 1;              /* the literal stream is reproducible with one thread only */
   pthread_t threads[256];
   for (i32 i = 1; i < n; i++) pthread_create(&threads[i], NULL, oracle_worker, &job);
   oracle_worker(&job);
   for (i32 i = 1; i < n; i++) pthread_join(threads[i], NULL);
   pthread_mutex_destroy(&job.lock);
+  tl_literal = false;                      /* unit-level entry points below always use the default semantics */
 
   if (counters) *counters = job.total;
   return 0;

@@ -15,7 +15,22 @@
  *   D4 asin argument clamped to [-1,1] in the background lookup;
  *   D5 no FMA contraction anywhere; libm replaced by include/rt_math.h;
  *   D6 default accumulation is order-free 32.32 fixed point (rt_math.h);
- *      ORACLE_ACCUM_F32 reproduces the reference's fp32 running sum.
+ *      ORACLE_ACCUM_F32 reproduces the reference's fp32 running sum;
+ *   D7 (builder, rt_scene_build.c) stable merge sort, early-leaf chain;
+ *   D8 expressions that the reference evaluates in DOUBLE because of unsuffixed literals are evaluated
+ *      stepwise in fp32: driver.c:220 `(2.0 * NDotV) / (...)` (smith_G), driver.c:238 `2.0 * PI * rand_f32()`,
+ *      :242 `(1.0 - s) * sqrt_f32(1.0 - t1 * t1) + s * t2` (one rounding in the reference, three here),
+ *      :246 `max(0.0, 1.0 - t1 * t1 - t2 * t2)`, driver.c:119 `rand_f32() * 2 * PI` and :96-97 `1.0f / PI`
+ *      (if codin's PI is a double), common.h:37 `1.0 / sqrt_f32(lensq)` (lightmap only).  driver.c:133 `2.0`,
+ *      :241 `0.5 * (1.0 + Vh.z)`, :416 `0.5` and common.h:84 `2.4` give the same f32 either way.  The GPU kernels
+ *      have no fp64 on the path; the difference is below 1 ulp per expression.
+ *
+ * ORACLE_LITERAL (Oracle_Config.literal = 1) switches D1, D2, D6 and D8 back to the reference's literal semantics:
+ * ONE thread whose RNG state is seeded once (frame seed in place of time_now(), raytracer.c:597) and runs on across
+ * pixels in chunk order, `_mm256_rsqrt_ps` for the primary directions (:663), fp32 running sum in sample order
+ * (:695-700), double intermediates at the D8 sites.  It cannot be bit-compared with anything (different random
+ * numbers per path); tests/test_oracle_literal.py checks that it and the default oracle are the same estimator:
+ * per-block means agree within the Monte-Carlo noise, with no bias.
  */
 #ifndef ORACLE_H
 #define ORACLE_H
@@ -55,6 +70,7 @@ typedef struct {
    * sample_count == 0 = all.  `samples` still names the pixel's total for
    * the RNG stream and the final mean.                                        */
   i32             sample0, sample_count;
+  i32             literal;         /* 1 = ORACLE_LITERAL (see the header comment)  */
 } Oracle_Config;
 
 /* Renders ctx-like arguments with the reference's semantics.

@@ -172,6 +172,8 @@ struct RT_Device_Scene {
   // launch state of this device scene: two device scenes can have launches in flight on two streams at once
   unsigned long long *counters = nullptr;      // RT_N_COUNTERS
   uint32_t           *work_head = nullptr;
+  uint32_t           *tile_next = nullptr;     // tile-stream kernel: chunks handed out per tile
+  int32_t             tile_next_n = 0;
   // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
   uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
   uint32_t    *order = nullptr, *hist = nullptr;
@@ -193,6 +195,7 @@ static void free_device_scene(RT_Device_Scene *d) {
   if (g_last_counters == d->counters) g_last_counters = nullptr;
   (void)hipFree(d->counters);
   (void)hipFree(d->work_head);
+  (void)hipFree(d->tile_next);
   (void)hipFree(d->cost[0]);
   (void)hipFree(d->cost[1]);
   (void)hipFree(d->order);
@@ -771,8 +774,11 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   }
   int n_waves = g_num_cus * waves_per_cu;
   if (n_waves > K.n_work) n_waves = K.n_work;
-  int variant = 3;     // 1 plain while-while, 2 phase-scheduled, 3 phase-scheduled + top of the BVH in LDS
+  // 1 plain while-while, 2 phase-scheduled, 3 phase-scheduled + top of the BVH in LDS, 4 = 3 + block statistics,
+  // 5 tile streams (per-tile chunk counters, work joining, inner traversal loop) + top of the BVH in LDS
+  int variant = 5;
   if (const char *e = getenv("RT_KERNEL")) variant = atoi(e);
+  if (variant < 1 || variant > 5) variant = 5;
   K.sched_thresh = 48;
   if (const char *e = getenv("RT_SCHED_THRESH")) {
     int v = atoi(e);
@@ -788,7 +794,6 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     smem = 4 * per_wave;
   } else if (variant != 1) {
     const int waves_per_block = 16;
-    if (variant != 4) variant = 3;
     int room = (lds_limit - waves_per_block * per_wave) / 208;
     if (room < 0) room = 0;
     K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
@@ -836,6 +841,30 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     d->sched_cur ^= 1;                // after this launch, cost[sched_cur ^ 1] is the buffer just written
     d->sched_key = key;
     d->sched_valid = true;
+  }
+
+  if (variant == 5) {
+    // chunk = one tile row (8 pixels) x `slab` samples, default 32: pixel-major inside the chunk, so 64 lanes sit on
+    // two pixels; 256 paths per chunk is also the granularity at which waves share a tile at the end of a launch
+    const int n_samples = K.sample_end - K.sample_first;
+    int cs = p->slab > 0 ? p->slab : 32;
+    int cshift = 0;
+    while ((1 << cshift) < cs && (1 << cshift) < n_samples) cshift++;
+    K.chunk_shift = cshift;
+    K.n_tiles = K.n_local_chunks * 16;
+    K.n_chunks_tile = 8 * ((n_samples + (1 << cshift) - 1) >> cshift);
+    if (d->tile_next_n < K.n_tiles) {
+      (void)hipFree(d->tile_next);
+      d->tile_next = nullptr;
+      d->tile_next_n = 0;
+      HIP_TRY(hipMalloc(&d->tile_next, (size_t)K.n_tiles * 4));
+      d->tile_next_n = K.n_tiles;
+    }
+    HIP_TRY(hipMemsetAsync(d->tile_next, 0, (size_t)K.n_tiles * 4, stream));
+    K.tile_next = d->tile_next;
+    int64_t chunks = (int64_t)K.n_tiles * K.n_chunks_tile;
+    n_waves = g_num_cus * waves_per_cu;
+    if ((int64_t)n_waves > chunks) n_waves = (int)chunks;
   }
 
   K.wave_times = nullptr;

@@ -90,6 +90,11 @@ typedef struct {
   const uint32_t *order;       /* tile visiting order (NULL = identity)   */
   uint32_t *tile_cost;         /* rays per tile of THIS launch (NULL = off)*/
   unsigned long long *wave_times; /* diagnostic kernel: per wave start, end (100 MHz), items */
+  /* tile-stream kernel (variant 5): a tile hands out chunks = one row of 8 pixels x (1 << chunk_shift) samples */
+  uint32_t *tile_next;         /* [n_tiles] chunks handed out so far (zero at launch)                       */
+  int32_t n_tiles;             /* n_local_chunks * 16                                                       */
+  int32_t chunk_shift;         /* log2 samples per chunk                                                    */
+  int32_t n_chunks_tile;       /* 8 rows x ceil(samples of this launch / samples per chunk)                 */
 } RT_KParams;
 
 #endif /* RT_DEVICE_H */

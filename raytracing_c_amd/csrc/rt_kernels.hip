@@ -1133,6 +1133,343 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 }
 
 // ---------------------------------------------------------------------------------
+// The tile-stream path kernel (default).  Same blocks and the same per-lane arithmetic as rt_path_kernel_sched;
+// what changes is where the work comes from and how the loop is cut:
+//
+//  * A wave OWNS an 8x8-pixel tile (taken from the head counter, expensive tiles first) and pulls CHUNKS of it --
+//    one row of 8 pixels x 2^chunk_shift samples -- from the tile's own counter `tile_next[tile]` until the tile is
+//    exhausted.  Lanes whose path ended are refilled across chunk boundaries, so there is no end-of-item drain
+//    between chunks (the scheduled kernel drains the wave at the end of every item, ~40 us each); the wave drains
+//    once per TILE.  Chunks are pixel-major, so the 64 lanes still sit on two or three pixels (coherent nodes,
+//    leaves and texels) whatever the chunk size.
+//  * When the head counter runs dry a wave JOINS a tile that still has chunks (scan of the most recently claimed
+//    tiles with agent-scope loads) and pulls from the same counter: the tail of a launch is balanced at chunk
+//    granularity (256 paths) even when a rank of the 8-GPU partition has fewer tiles than the chip has waves.
+//    Every chunk is handed out exactly once by an atomic; radiance sums are order-free integers, so results do
+//    not depend on who traced what.  Owners always finish their tile, so a joiner may give up at any time:
+//    every wave reaches an exit (bounded scans), there is no inter-wave dependency and no grid barrier.
+//  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
+//    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
+//    two ballots, and the counters are wave-level scalars.
+#define RT_STEAL_WINDOW 4096      // most recently claimed tiles a joining wave looks at
+#define RT_STEAL_TRIES  16        // failed joins before a wave retires
+
+template <int WAVES, bool LDSN, int MIN_WAVES_PER_SIMD = 1>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel_stream(RT_KParams P) {
+  extern __shared__ float4 smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n_lds = LDSN ? P.n_lds_nodes : 0;
+  const float4 *lds_nodes = smem;
+  const int perm_f4 = (P.depth > 0 ? P.depth : 1) * 16;
+  float4 *wave_base = smem + n_lds * RT_LDS_NODE_F4 + wave * (perm_f4 + 96);
+  uint32_t *perm = reinterpret_cast<uint32_t *>(wave_base);
+  unsigned long long *acc = reinterpret_cast<unsigned long long *>(wave_base + perm_f4);
+
+  if (LDSN) {
+    const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
+    for (int i = threadIdx.x; i < n_lds * 12; i += WAVES * 64) {
+      int nd = i / 12, q = i - nd * 12;
+      smem[nd * RT_LDS_NODE_F4 + q] = g[i];
+    }
+    __syncthreads();          // the only workgroup barrier of the kernel; waves are independent afterwards
+  }
+
+  acc[lane] = 0ull;
+  acc[lane + 64] = 0ull;
+  acc[lane + 128] = 0ull;
+
+  // wave-level counters (scalar registers)
+  uint32_t w_paths = 0, w_rays = 0, w_nodes = 0, w_leaves = 0, w_shades = 0, w_bgs = 0, w_tex = 0;
+
+  const int shift = P.chunk_shift;                 // samples per chunk = 1 << shift
+  const int chunk_paths = 8 << shift;              // 8 pixels of one tile row
+  const uint32_t n_chunks_tile = (uint32_t)P.n_chunks_tile;
+  const int leaf_level = P.depth - 1;
+  const int thresh = P.sched_thresh;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  const int wave_id = (int)blockIdx.x * WAVES + wave;
+
+  bool queue_open = true;
+  int  steal_tries = 0;
+
+  for (;;) {
+    // ---------------- take a tile: own one from the queue, or join one that still has chunks ----------------
+    int tile_idx = -1;
+    if (queue_open) {
+      uint32_t pos = 0;
+      if (lane == 0) pos = atomicAdd(P.work_head, 1u);
+      pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+      if (pos < (uint32_t)P.n_tiles) tile_idx = P.order ? (int)P.order[pos] : (int)pos;
+      else queue_open = false;
+    }
+    if (tile_idx < 0) {
+      if (steal_tries >= RT_STEAL_TRIES) break;
+      steal_tries += 1;
+      // tiles are claimed in queue order, so the ones still in progress are the last ones claimed
+      const int window = P.n_tiles < RT_STEAL_WINDOW ? P.n_tiles : RT_STEAL_WINDOW;
+      const int rounds = (window + 63) >> 6;
+      const int start = (int)(((uint32_t)wave_id * 2654435761u + (uint32_t)steal_tries * 40503u) >> 8) % rounds;
+      for (int i = 0; i < rounds && tile_idx < 0; i++) {
+        int r = start + i;
+        if (r >= rounds) r -= rounds;
+        int off = r * 64 + lane;
+        int cand = -1;
+        uint32_t taken = 0xFFFFFFFFu;
+        if (off < window) {
+          int pos = P.n_tiles - 1 - off;
+          cand = P.order ? (int)P.order[pos] : pos;
+          taken = __hip_atomic_load(&P.tile_next[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long open = __ballot(taken < n_chunks_tile);
+        if (open) {
+          // one of the open tiles of this group, not always the first: joiners spread over them
+          int nth = (int)(((uint32_t)wave_id >> 2) % (uint32_t)__popcll(open));
+          unsigned long long m = open;
+          for (int k = 0; k < nth; k++) m &= m - 1ull;
+          int src = (int)__builtin_ctzll(m);
+          tile_idx = __builtin_amdgcn_readlane(cand, src);
+        }
+      }
+      if (tile_idx < 0) break;                      // nothing left to join
+    }
+
+    const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
+    const int chunk = P.local_chunks[lchunk];
+    const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
+    const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
+    if (tile_x0 >= P.width || tile_y0 >= P.height) {
+      // tile entirely outside the image: mark it exhausted so that no wave tries to join it
+      if (lane == 0) atomicMax(&P.tile_next[tile_idx], n_chunks_tile);
+      continue;
+    }
+    const uint32_t rays_before = w_rays;
+
+    // ---------------- per-lane state ----------------
+    int   phase = PH_NEED;
+    int   pix = 0, bounce = 0;
+    uint32_t rng = 0;
+    Ray3  ray;
+    ray_setup(ray, rt_v3_make(0, 0, 0), rt_v3_make(0, 0, 1));
+    rt_v3 tint = rt_v3_make(1, 1, 1), emis = rt_v3_make(0, 0, 0);
+    int   level = -1, node = 0, child = 0;
+    uint32_t cur = 0, dirty = 0, live = 0;
+    HitRec hit;
+    hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+
+    // current chunk of the tile (wave-uniform): paths [c_next, c_end) of row c_y, samples from c_s0
+    bool tile_open = true;
+    int  c_next = 0, c_end = 0, c_y = 0, c_row = 0, c_s0 = 0;
+    bool took_any = false;
+
+    for (;;) {
+      // ================= S: shade the hits, environment for the misses, start new paths =================
+      {
+        LaneCounters cn;
+        cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
+        bool  done = false, start = false;
+        rt_v3 radiance = rt_v3_make(0, 0, 0);
+        rt_v3 org = ray.o, dir = ray.d;
+        if (phase == PH_HIT) {
+          done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
+          start = !done;
+        } else if (phase == PH_MISS) {
+          cn.bgs = 1;
+          rt_v3 bg = background_lookup(P, dir);
+          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
+          done = true;
+        }
+        if (done) {
+          atomicAdd(&acc[pix * 3 + 0], (unsigned long long)rt_accum_quantize(radiance.x));
+          atomicAdd(&acc[pix * 3 + 1], (unsigned long long)rt_accum_quantize(radiance.y));
+          atomicAdd(&acc[pix * 3 + 2], (unsigned long long)rt_accum_quantize(radiance.z));
+          phase = PH_NEED;
+        }
+        w_shades += (uint32_t)__popcll(__ballot(cn.shades != 0));
+        w_tex += (uint32_t)__popcll(__ballot(cn.textured != 0));
+        w_bgs += (uint32_t)__popcll(__ballot(cn.bgs != 0));
+
+        // ---- regeneration: idle lanes take the next paths of the tile, across chunk boundaries ----
+        if (tile_open) {
+          unsigned long long need = __ballot(phase == PH_NEED);
+          bool got = false;
+          int  gx = 0, gy = 0, gs = 0, gp = 0;
+          while (need) {
+            if (c_next >= c_end) {
+              uint32_t c = 0;
+              if (lane == 0) c = atomicAdd(&P.tile_next[tile_idx], 1u);
+              c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+              if (c >= n_chunks_tile) { tile_open = false; break; }
+              took_any = true;
+              c_row = (int)(c & 7u);
+              c_y = tile_y0 + c_row;
+              c_s0 = P.sample_first + (int)((c >> 3) << shift);
+              c_next = 0;
+              c_end = (c_y < P.height) ? chunk_paths : 0;      // a row below the image has no paths
+              continue;
+            }
+            const int n_need = (int)__popcll(need);
+            const int avail = c_end - c_next;
+            const int take = n_need < avail ? n_need : avail;
+            const int rank = (int)__popcll(need & lane_lt);
+            bool valid = false;
+            if (((need >> lane) & 1ull) && rank < take) {
+              // k -> (pixel of the row, sample of the chunk), pixel-major: the lanes of a wave stay on a few pixels
+              int k = c_next + rank;
+              int px = k >> shift;
+              int sm = c_s0 + (k & ((1 << shift) - 1));
+              int x = tile_x0 + px;
+              if (x < P.width && sm < P.sample_end) {
+                valid = true;
+                if (P.max_bounces > 0) { got = true; gx = x; gy = c_y; gs = sm; gp = c_row * 8 + px; }
+                // max_bounces == 0: the path exists and is black (the loop of raytracer.c:512 runs zero times)
+              }
+            }
+            w_paths += (uint32_t)__popcll(__ballot(valid));
+            c_next += take;
+            need = __ballot(phase == PH_NEED && !got);
+          }
+          if (got) {
+            pix = gp;
+            bounce = 0;
+            rng = rt_path_seed(P.seed, (uint32_t)(gx + gy * P.width), (uint32_t)gs);
+            primary_ray(P, gx, gy, gs, org, dir);
+            tint = rt_v3_make(1, 1, 1);
+            emis = rt_v3_make(0, 0, 0);
+            start = true;
+          }
+        }
+        if (start) {                      // a new ray: traversal starts at the root (or at leaf group 0)
+          ray_setup(ray, org, dir);
+          hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+          dirty = 0;
+          live = 0;
+          cur = 0;
+          level = -1;
+          node = 0;
+          child = (P.depth > 0) ? 0 : P.last_row_offset;
+          phase = (P.depth > 0) ? PH_NODE : PH_LEAF;
+        }
+        w_rays += (uint32_t)__popcll(__ballot(start));
+      }
+
+      const int n_trav0 = (int)__popcll(__ballot(phase == PH_NODE || phase == PH_LEAF));
+      if (n_trav0 == 0) {
+        if (!tile_open) break;            // every path of the tile that this wave took has ended
+        continue;                         // (nothing started, e.g. pixels outside the image: pull more)
+      }
+
+      // ================= traversal: NODE / LEAF blocks until `thresh` lanes wait for S =================
+      for (;;) {
+        const int nN = (int)__popcll(__ballot(phase == PH_NODE));
+        const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
+        if (nN + nL == 0 || n_trav0 - (nN + nL) >= thresh) break;
+
+        if (nL >= nN) {
+          // ----- LEAF -----
+          w_leaves += (uint32_t)nL;
+          if (phase == PH_LEAF) {
+            int  g = child - P.last_row_offset;
+            bool got = leaf_test<false>(P, ray, g, hit);
+            if (got) dirty = 0xFFFFFFFFu;
+            phase = PH_POP;
+          }
+        } else {
+          // ----- NODE -----
+          w_nodes += (uint32_t)nN;
+          const bool all_fast = __ballot(phase == PH_NODE && !ray.fast) == 0;
+          if (phase == PH_NODE) {
+            if (level >= 0) {
+              perm[level * 64 + lane] = cur;
+              live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
+            }
+            node = child;
+            level += 1;
+            if (all_fast) {
+              if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes);
+              else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+            } else {
+              cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+            }
+            dirty &= ~(1u << level);
+            if (cur >> 24) {
+              child = 8 * node + 1 + (int)(cur & 7u);
+              cur = ((cur >> 3) & 0x1FFFFFu) | (((cur >> 24) - 1u) << 24);
+              phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
+            } else {
+              phase = PH_POP;
+            }
+          }
+        }
+
+        // ----- pops: every lane that just finished a block takes its next child / goes up -----
+        while (__any(phase == PH_POP)) {
+          if (phase == PH_POP) {
+            uint32_t cnt = cur >> 24;
+            if (cnt == 0 || level < 0) {
+              uint32_t above = (level > 0) ? (live & ((1u << level) - 1u)) : 0u;
+              if (above == 0u) {
+                level = -1;
+                phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
+              } else {
+                int target = 31 - __clz((int)above);
+                int k3 = 3 * (level - target);
+                node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
+                level = target;
+                cur = perm[level * 64 + lane];
+                cnt = cur >> 24;
+              }
+            }
+            if (phase == PH_POP) {
+              int j = (int)(cur & 7u);
+              cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
+              bool go = true;
+              if ((dirty >> level) & 1u) {
+                float dj;
+                if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4) + j, ray);
+                else dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
+                if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
+              }
+              if (go) {
+                child = 8 * node + 1 + j;
+                phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---------------- flush the wave's share of the tile: lane p owns pixel p ----------------
+    if (took_any) {
+      int x = tile_x0 + (lane & 7), y = tile_y0 + (lane >> 3);
+      unsigned long long r = acc[lane * 3 + 0], g = acc[lane * 3 + 1], b = acc[lane * 3 + 2];
+      acc[lane * 3 + 0] = 0ull;
+      acc[lane * 3 + 1] = 0ull;
+      acc[lane * 3 + 2] = 0ull;
+      if (x < P.width && y < P.height && (r | g | b) != 0ull) {
+        unsigned long long *dst = P.accum + ((size_t)y * P.width + x) * 3;
+        atomicAdd(dst + 0, r);
+        atomicAdd(dst + 1, g);
+        atomicAdd(dst + 2, b);
+      }
+      if (P.tile_cost && lane == 0) atomicAdd(&P.tile_cost[tile_idx], w_rays - rays_before);
+      steal_tries = 0;                    // joined (or owned) a tile that had work: keep looking for more
+    }
+  }
+
+  if (lane == 0) {
+    atomicAdd(P.counters + CNT_PATHS, (unsigned long long)w_paths);
+    atomicAdd(P.counters + CNT_RAYS, (unsigned long long)w_rays);
+    atomicAdd(P.counters + CNT_NODES, (unsigned long long)w_nodes);
+    atomicAdd(P.counters + CNT_LEAVES, (unsigned long long)w_leaves);
+    atomicAdd(P.counters + CNT_SHADES, (unsigned long long)w_shades);
+    atomicAdd(P.counters + CNT_BG, (unsigned long long)w_bgs);
+    atomicAdd(P.counters + CNT_TEXTURED, (unsigned long long)w_tex);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // accum -> mean -> clamp -> sRGB -> u8 (raytracer.c:700-716), one thread per pixel
 // of this rank's chunks.
 __global__ void rt_resolve_kernel(int width, int height, int samples, int chunks_x, const int32_t *local_chunks,
@@ -1446,8 +1783,23 @@ static int launch_sched(const RT_KParams *P, int n_waves, int smem_bytes, hipStr
   return (int)hipGetLastError();
 }
 
+template <int WAVES, bool LDSN, int MINW>
+static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set && smem_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_stream<WAVES, LDSN, MINW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rt_path_kernel_stream<WAVES, LDSN, MINW>), dim3((n_waves + WAVES - 1) / WAVES), dim3(WAVES * 64),
+                     smem_bytes, stream, *P);
+  return (int)hipGetLastError();
+}
+
 extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
   switch (variant) {
+  case 5: return launch_stream<16, true, 1>(P, n_waves, smem_bytes, stream);
   case 1:
     hipLaunchKernelGGL(rt_path_kernel, dim3((n_waves + 3) / 4), dim3(RT_BLOCK_THREADS), 0, stream, *P);
     return (int)hipGetLastError();

@@ -24,7 +24,7 @@ class Oracle_Config(C.Structure):
     _fields_ = [("disney_proc", C.c_void_p), ("debug_proc", C.c_void_p), ("background_proc", C.c_void_p),
                 ("seed", C.c_uint32), ("accum_mode", C.c_int32), ("n_threads", C.c_int32),
                 ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
-                ("sample0", C.c_int32), ("sample_count", C.c_int32)]
+                ("sample0", C.c_int32), ("sample_count", C.c_int32), ("literal", C.c_int32)]
 
 
 _dll = None
@@ -79,7 +79,7 @@ def load(path=None):
     return d
 
 
-def config_for(hs, seed=0x1234ABCD, n_threads=8, accum_mode=0, window=None, samples=None):
+def config_for(hs, seed=0x1234ABCD, n_threads=8, accum_mode=0, window=None, samples=None, literal=False):
     """Oracle_Config whose built-in material addresses are the product's exported tokens."""
     from raytracing_c_amd.native import symbol_address
     cfg = Oracle_Config()
@@ -93,11 +93,12 @@ def config_for(hs, seed=0x1234ABCD, n_threads=8, accum_mode=0, window=None, samp
         cfg.x0, cfg.y0, cfg.x1, cfg.y1 = window
     if samples:
         cfg.sample0, cfg.sample_count = samples
+    cfg.literal = 1 if literal else 0
     return cfg
 
 
 def render(hs, width, height, samples, max_bounces, seed=0x1234ABCD, n_threads=8, accum_mode=0, window=None,
-           sample_range=None, lib=None):
+           sample_range=None, lib=None, literal=False):
     """Oracle render -> dict(image, linear, accum, counters)."""
     d = lib or load()
     out = np.zeros((height, width, 3), np.uint8)
@@ -106,7 +107,7 @@ def render(hs, width, height, samples, max_bounces, seed=0x1234ABCD, n_threads=8
     img.pixels.data, img.pixels.len = out.ctypes.data, out.size
     linear = np.zeros((height, width, 3), np.float32)
     accum = np.zeros((height, width, 3), np.uint64)
-    cfg = config_for(hs, seed, n_threads, accum_mode, window, sample_range)
+    cfg = config_for(hs, seed, n_threads, accum_mode, window, sample_range, literal)
     cnt = Oracle_Counters()
     rc = d.oracle_render(C.byref(hs.scene), C.byref(img), samples, max_bounces, C.byref(cfg), linear.ctypes.data,
                          accum.ctypes.data, C.byref(cnt))

@@ -200,9 +200,9 @@ def test_frame_bit_exact(rt, oracle, name, w, h, s, b, shader):
     assert want["image"].std() > 1.0, "frame must not be blank"
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5])
 def test_every_kernel_variant_is_bit_exact(rt, oracle, variant, monkeypatch):
-    """RT_KERNEL=1 plain while-while kernel, 2 phase-scheduled, 3 phase-scheduled + BVH top in LDS (default)."""
+    """RT_KERNEL=1 plain while-while kernel, 2 phase-scheduled, 3 phase-scheduled + BVH top in LDS, 5 tile streams (default)."""
     from raytracing_c_amd.configs import load_config
     from tests import _oracle
     monkeypatch.setenv("RT_KERNEL", str(variant))
