@@ -154,7 +154,15 @@ static inline isize bvh_n_internal_nodes(isize depth) {
  *     reading nodes[0] out of bounds (raytracer.c:451). */
 extern void scene_init(Scene *scene, Triangle_Slice src_triangles, Allocator allocator);
 
-/* Releases what scene_init allocated with the default allocator. */
+/* Opt-in quality builder (the reference has none): surface-area-heuristic build into the
+ * SAME implicit 8-ary layout -- same depth, node format, leaf-group addressing -- so everything that consumes a
+ * Scene (render_thread_proc, lightmap_bake, the .scene file, the CPU oracle) works on it unchanged.  Fewer
+ * box and triangle tests per ray; the image can differ from a scene_init() scene only where two triangles
+ * are hit at exactly the same distance (the tie goes to the lower slot, raytracer.c:27-29,159). */
+extern void scene_init_sah(Scene *scene, Triangle_Slice src_triangles, Allocator allocator);
+
+/* Releases what scene_init / scene_init_sah allocated with the default allocator (blocks from a caller's
+ * Allocator and scenes that alias a file buffer are left alone) and drops the device copy of the scene. */
 extern void rt_scene_free(Scene *scene);
 
 /* The `.scene` cache file, reference scene.h:99-100 / scene.c:13-76: a 96-byte header

@@ -21,7 +21,9 @@ CONFIGS = {
 }
 
 
-def load_config(name, shader="disney"):
+def load_config(name, shader="disney", builder="reference"):
+    """builder: "reference" = scene_init (the reference's split, scene.c:311-414; every headline number) or "sah" =
+    scene_init_sah (opt-in quality builder emitting the same layout)."""
     asset, w, h, s, b, cam = CONFIGS[name]
-    hs = load_model(os.path.join(ASSETS, asset), camera=cam, shader=shader)
+    hs = load_model(os.path.join(ASSETS, asset), camera=cam, shader=shader, builder=builder)
     return hs, dict(width=w, height=h, samples=s, max_bounces=b, asset=asset)

@@ -339,6 +339,172 @@ void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
   free(work); free(sb.keys); free(sb.tmp); free(sb.scratch);
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * scene_init_sah() -- opt-in quality builder: a surface-area-heuristic build that
+ * emits the SAME layout as scene_init() (implicit complete 8-ary tree of bvh_required_depth(n) levels,
+ * BVH_Node boxes, leaf groups of 8 triangles in the last row, unused children all-zero), so the render path
+ * -- CPU oracle and GPU kernels alike -- traverses it unchanged.  The reference's split (scene.c:311-414)
+ * packs every leaf group full and cuts each node's triangles at multiples of the child capacity, wherever
+ * that falls in space; half of the leaf slots of the complete tree stay empty (helmet: 1 932 of 4 096).
+ * This builder spends that slack on tighter boxes:
+ *   - a node's triangles are cut into up to 8 children by repeated binary splits; the cut of a slice is the
+ *     position (sweep over the centroid order of each axis) that minimises
+ *         area(left) * (n_left + 8) + area(right) * (n_right + 8)
+ *     -- the triangles below a child plus the 8-wide test the child itself costs, whether it holds 1 or 8
+ *     triangles (raytracer.c:84-188 always tests 8);
+ *   - a cut is only taken if every child still fits its subtree (8^depth triangles) and the node keeps at
+ *     most 8 children: sum over slices of ceil(len / capacity) <= 8 is the invariant;
+ *   - the slice with the largest area * (len + 8) is cut next; slices over capacity are cut first; a cut that
+ *     does not lower the cost is not taken.
+ * Deterministic (stable sorts, no threads). */
+typedef struct { Triangle *data; isize len; AABB box; f32 area; bool final; } Sah_Slice;
+
+typedef struct {
+  Sort_Buffers sb;
+  AABB        *suffix;      /* suffix[i] = box of triangles [i, len) of the slice being swept */
+} Sah_Buffers;
+
+static void aabb_grow(AABB *a, AABB const *t) {
+  for (int ax = 0; ax < 3; ax++) {
+    if (t->min.data[ax] < a->min.data[ax]) a->min.data[ax] = t->min.data[ax];
+    if (t->max.data[ax] > a->max.data[ax]) a->max.data[ax] = t->max.data[ax];
+  }
+}
+
+static isize ceil_div(isize a, isize b) { return (a + b - 1) / b; }
+/* cost weight of a child holding n triangles: the triangles below it plus one 8-wide test of its own.  Measured
+ * against the alternatives on the three asset scenes with the oracle's counters (node / leaf visits per ray, helmet):
+ * ceil(n/8) 3.276 / 0.992, n 3.215 / 1.256, n + 8 3.205 / 0.962 (reference split: 3.378 / 1.232). */
+static f32 sah_w(isize n) { return (f32)n + (f32)RT_BVH_WIDTH; }
+
+/* best cut of `s` on the axis it is currently sorted by; returns the cost, writes the position */
+static f32 sah_sweep(Sah_Slice const *s, isize capacity, isize other_slots, Sah_Buffers *sb, isize *pos_out) {
+  isize n = s->len;
+  AABB run;
+  for (isize i = n - 1; i >= 0; i--) {
+    AABB t;
+    aabb_triangle(&s->data[i], &t);
+    if (i == n - 1) run = t; else aabb_grow(&run, &t);
+    sb->suffix[i] = run;
+  }
+  f32 best = RT_INF;
+  *pos_out = -1;
+  for (isize i = 1; i < n; i++) {
+    AABB t;
+    aabb_triangle(&s->data[i - 1], &t);
+    if (i == 1) run = t; else aabb_grow(&run, &t);
+    if (other_slots + ceil_div(i, capacity) + ceil_div(n - i, capacity) > RT_BVH_WIDTH) continue;
+    f32 cost = aabb_surface_area(&run) * sah_w(i) +
+               aabb_surface_area(&sb->suffix[i]) * sah_w(n - i);
+    if (cost < best) { best = cost; *pos_out = i; }
+  }
+  return best;
+}
+
+static void sah_build(Scene *scene, Triangle *tris, isize count, isize depth, BVH_Index index, Sah_Buffers *sb) {
+  if (count == 0) return;
+  if (depth == 0) {
+    triangles_insert(&scene->triangles, tris, count, ((isize)index - scene->bvh.last_row_offset) * RT_BVH_WIDTH);
+    return;
+  }
+  isize capacity = bvh_n_leaf_nodes(depth);          /* triangles one child subtree can hold */
+
+  Sah_Slice slices[RT_BVH_WIDTH];
+  isize n_slices = 1;
+  slices[0].data = tris;
+  slices[0].len = count;
+  slices[0].final = false;
+  aabb_triangle_slice(tris, count, &slices[0].box);
+  slices[0].area = aabb_surface_area(&slices[0].box);
+
+  for (;;) {
+    /* next slice to cut: over-capacity ones first (they must be cut), then the most expensive one */
+    isize pick = -1;
+    f32 pick_key = -1.0f;
+    bool forced = false;
+    for (isize i = 0; i < n_slices; i++) {
+      Sah_Slice *s = &slices[i];
+      if (s->len > capacity) {
+        if (!forced || s->len > slices[pick].len) { pick = i; forced = true; }
+      } else if (!forced && !s->final && s->len >= 2 && n_slices < RT_BVH_WIDTH) {
+        f32 key = s->area * sah_w(s->len);
+        if (key > pick_key) { pick_key = key; pick = i; }
+      }
+    }
+    if (pick < 0) break;
+    Sah_Slice *s = &slices[pick];
+    isize other_slots = 0;
+    for (isize i = 0; i < n_slices; i++) if (i != pick) other_slots += ceil_div(slices[i].len, capacity);
+
+    f32 best_cost = RT_INF;
+    int best_axis = -1;
+    isize best_pos = -1;
+    for (int axis = 0; axis < 3; axis++) {
+      sort_triangle_slice(s->data, s->len, axis, &sb->sb);
+      isize pos;
+      f32 cost = sah_sweep(s, capacity, other_slots, sb, &pos);
+      if (pos > 0 && cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = pos; }
+    }
+    f32 whole = s->area * sah_w(s->len);
+    if (best_axis < 0 || (!forced && !(best_cost < whole))) {
+      /* (a forced slice always has a feasible cut: the invariant sum ceil(len / capacity) <= 8 holds) */
+      s->final = true;
+      if (forced) break;                               /* unreachable; guards against an endless loop */
+      continue;
+    }
+    if (best_axis != 2) sort_triangle_slice(s->data, s->len, best_axis, &sb->sb);
+    Sah_Slice left, right;
+    left.data = s->data;             left.len = best_pos;           left.final = false;
+    right.data = s->data + best_pos; right.len = s->len - best_pos; right.final = false;
+    aabb_triangle_slice(left.data, left.len, &left.box);
+    aabb_triangle_slice(right.data, right.len, &right.box);
+    left.area = aabb_surface_area(&left.box);
+    right.area = aabb_surface_area(&right.box);
+    slices[pick] = left;
+    slices[n_slices++] = right;
+  }
+
+  BVH_Node node;
+  memset(&node, 0, sizeof node);
+  for (isize i = 0; i < n_slices; i++) {
+    node.min_x[i] = slices[i].box.min.x; node.min_y[i] = slices[i].box.min.y; node.min_z[i] = slices[i].box.min.z;
+    node.max_x[i] = slices[i].box.max.x; node.max_y[i] = slices[i].box.max.y; node.max_z[i] = slices[i].box.max.z;
+  }
+  scene->bvh.nodes.data[index] = node;
+  for (isize i = 0; i < n_slices; i++)
+    sah_build(scene, slices[i].data, slices[i].len, depth - 1, index * RT_BVH_WIDTH + 1 + (BVH_Index)i, sb);
+}
+
+void scene_init_sah(Scene *scene, Triangle_Slice src, Allocator allocator) {
+  if (rt_scene_invalidate) rt_scene_invalidate(scene);
+  isize depth      = bvh_required_depth(src.len);
+  isize n_internal = bvh_n_internal_nodes(depth);
+  scene->bvh.depth           = depth;
+  scene->bvh.last_row_offset = n_internal;
+  scene->bvh.nodes.len       = n_internal;
+  scene->bvh.nodes.data      = (BVH_Node *)rt_alloc_zeroed(allocator, n_internal * (isize)sizeof(BVH_Node), 64);
+  memset(&scene->triangles, 0, sizeof scene->triangles);
+  if (!scene->bvh.nodes.data) { scene->bvh.nodes.len = 0; return; }
+  if (!triangles_init(&scene->triangles, bvh_n_leaf_nodes(depth) * RT_BVH_WIDTH, allocator)) {
+    memset(&scene->triangles, 0, sizeof scene->triangles);
+    return;
+  }
+  if (src.len <= 0) return;
+
+  isize n = src.len;
+  Triangle *work = (Triangle *)malloc((size_t)n * sizeof *work);
+  Sah_Buffers sb;
+  sb.sb.keys    = (Sort_Key *)malloc((size_t)n * sizeof *sb.sb.keys);
+  sb.sb.tmp     = (Sort_Key *)malloc((size_t)n * sizeof *sb.sb.tmp);
+  sb.sb.scratch = (Triangle *)malloc((size_t)n * sizeof *sb.sb.scratch);
+  sb.suffix     = (AABB *)malloc((size_t)n * sizeof *sb.suffix);
+  if (work && sb.sb.keys && sb.sb.tmp && sb.sb.scratch && sb.suffix) {
+    memcpy(work, src.data, (size_t)n * sizeof *work);
+    sah_build(scene, work, n, depth, 0, &sb);
+  }
+  free(work); free(sb.sb.keys); free(sb.sb.tmp); free(sb.sb.scratch); free(sb.suffix);
+}
+
 /* Releases what scene_init() allocated with the DEFAULT allocator and drops the device copy.  Blocks that came from
  * a caller's Allocator, or that alias a file buffer (scene_load_bytes), are not touched: they are the caller's. */
 void rt_scene_free(Scene *scene) {

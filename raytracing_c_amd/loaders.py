@@ -341,10 +341,10 @@ def load_model_data(path):
     raise ValueError(f"Unrecognized file type: '{path}'")
 
 
-def load_model(path, camera=None, background=None, shader="disney"):
+def load_model(path, camera=None, background=None, shader="disney", builder="reference"):
     """File -> HostScene.  camera = (4x4 matrix, yfov) overrides the file's / the default camera."""
     d = load_model_data(path)
     cam = camera or d["camera"] or default_camera()
     bg = background if background is not None else procedural_background()
     return build_scene(d["positions"], d["normals"], d["uvs"], d["material_ids"], d["materials"], d["images"],
-                       cam[0], cam[1], bg, shader=shader)
+                       cam[0], cam[1], bg, shader=shader, builder=builder)

@@ -81,6 +81,8 @@ def _declare(d):
     d.rt_get_seed.restype = C.c_uint32
     d.scene_init.argtypes = [P(abi.Scene), abi.Triangle_Slice, abi.Allocator]
     d.scene_init.restype = None
+    d.scene_init_sah.argtypes = [P(abi.Scene), abi.Triangle_Slice, abi.Allocator]
+    d.scene_init_sah.restype = None
     d.rt_scene_free.argtypes = [P(abi.Scene)]
     d.rt_scene_free.restype = None
     d.scene_load_bytes.argtypes = [abi.Byte_Slice, P(abi.Scene)]

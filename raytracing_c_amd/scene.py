@@ -130,7 +130,7 @@ class HostScene:
 
 
 def build_scene(positions, normals, uvs, material_ids, materials: List[Material], images, camera_matrix, yfov,
-                background, shader="disney") -> HostScene:
+                background, shader="disney", builder="reference") -> HostScene:
     """positions/normals: (N,3,3) f32, uvs: (N,3,2) f32, material_ids: (N,) int,
     images: list of (H,W,C) uint8, background: (H,W,C) uint8 equirect sRGB."""
     positions = np.ascontiguousarray(positions, np.float32)
@@ -191,7 +191,13 @@ def build_scene(positions, normals, uvs, material_ids, materials: List[Material]
 
     sl = abi.Triangle_Slice(tri.ctypes.data, n)
     t0 = time.perf_counter()
-    lib.scene_init(C.byref(hs.scene), sl, abi.Allocator(None, None))
+    if builder == "reference":
+        lib.scene_init(C.byref(hs.scene), sl, abi.Allocator(None, None))          # scene.c:416-426
+    elif builder == "sah":
+        lib.scene_init_sah(C.byref(hs.scene), sl, abi.Allocator(None, None))      # opt-in quality builder, same layout
+    else:
+        raise ValueError(f"unknown BVH builder {builder!r}")
+    hs.builder = builder
     hs.scene_init_seconds = time.perf_counter() - t0
     if not hs.scene.triangles.x[0]:
         raise MemoryError("scene_init failed")
