@@ -32,6 +32,7 @@ int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *o
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
 int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int lw, int lh, int stride, int comp,
                        int samples, int *owner, uint8_t *pixels, hipStream_t stream);
+int rt_launch_stream_init(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, hipStream_t stream);
 int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
@@ -844,31 +845,50 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   }
 
   if (variant == 5) {
-    // chunk = one tile row (8 pixels) x `slab` samples, default 32: pixel-major inside the chunk, so 64 lanes sit on
-    // two pixels; 256 paths per chunk is also the granularity at which waves share a tile at the end of a launch
+    // unit = 2 neighbouring pixels x `slab` samples, default 32 (64 paths, pixel-major: the 64 lanes sit on two pixels);
+    // it is also the granularity at which waves share a tile at the end of a launch
     const int n_samples = K.sample_end - K.sample_first;
     int cs = p->slab > 0 ? p->slab : 32;
     int cshift = 0;
     while ((1 << cshift) < cs && (1 << cshift) < n_samples) cshift++;
     K.chunk_shift = cshift;
     K.n_tiles = K.n_local_chunks * 16;
-    K.n_chunks_tile = 8 * ((n_samples + (1 << cshift) - 1) >> cshift);
+    K.n_sample_blocks = (n_samples + (1 << cshift) - 1) >> cshift;
+    K.n_chunks_tile = 32 * K.n_sample_blocks;          // units: 8 rows x sample blocks x 4 pixel pairs
+    K.drain_thresh = K.sched_thresh;
+    if (const char *e = getenv("RT_DRAIN_THRESH")) {
+      int v = atoi(e);
+      if (v >= 1 && v <= 64) K.drain_thresh = v;
+    }
     if (d->tile_next_n < K.n_tiles) {
       (void)hipFree(d->tile_next);
       d->tile_next = nullptr;
       d->tile_next_n = 0;
-      HIP_TRY(hipMalloc(&d->tile_next, (size_t)K.n_tiles * 4));
+      // [n_tiles] chunk counters, then [ceil(n_tiles / 64)] open-tile counts of the groups
+      HIP_TRY(hipMalloc(&d->tile_next, ((size_t)K.n_tiles + (size_t)((K.n_tiles + 63) / 64)) * 4));
       d->tile_next_n = K.n_tiles;
     }
-    HIP_TRY(hipMemsetAsync(d->tile_next, 0, (size_t)K.n_tiles * 4, stream));
     K.tile_next = d->tile_next;
+    K.open_groups = d->tile_next + d->tile_next_n;
+    {
+      int rc2 = rt_launch_stream_init(K.n_tiles, K.tile_next, K.open_groups, stream);
+      if (rc2 != 0) return rt_fail("stream init kernel failed: %s", hipGetErrorString((hipError_t)rc2));
+    }
     int64_t chunks = (int64_t)K.n_tiles * K.n_chunks_tile;
     n_waves = g_num_cus * waves_per_cu;
     if ((int64_t)n_waves > chunks) n_waves = (int)chunks;
+    // units per atomic: 2 (measured, helmet frame: 4 -> 47.27 ms, 2 -> 47.19, 1 -> 47.45); 1 when the launch has few tiles
+    // per wave (a rank of the 8-GPU partition: 4 -> 6.97 / 7.14 / 6.79 ms, 2 -> 6.72 / 6.77 / 6.46, 1 -> 6.65 / 6.66 / 6.45):
+    // what a wave still holds when the launch runs dry is its tail
+    K.grab_max = (int64_t)K.n_tiles < (int64_t)2 * n_waves ? 1 : 2;
+    if (const char *e = getenv("RT_GRAB")) {
+      int v = atoi(e);
+      if (v == 1 || v == 2 || v == 4) K.grab_max = v;
+    }
   }
 
   K.wave_times = nullptr;
-  if (variant == 4) {
+  if (variant == 4 || (variant == 5 && getenv("RT_WAVE_TIMES"))) {      // wave timeline (tools/exp_waves.py)
     if (!g_ws.wave_times) HIP_TRY(hipMalloc(&g_ws.wave_times, (size_t)65536 * 3 * 8));
     HIP_TRY(hipMemsetAsync(g_ws.wave_times, 0, (size_t)65536 * 3 * 8, stream));
     K.wave_times = g_ws.wave_times;

@@ -90,11 +90,15 @@ typedef struct {
   const uint32_t *order;       /* tile visiting order (NULL = identity)   */
   uint32_t *tile_cost;         /* rays per tile of THIS launch (NULL = off)*/
   unsigned long long *wave_times; /* diagnostic kernel: per wave start, end (100 MHz), items */
-  /* tile-stream kernel (variant 5): a tile hands out chunks = one row of 8 pixels x (1 << chunk_shift) samples */
+  /* tile-stream kernel (variant 5): a tile hands out units = 2 pixels x (1 << chunk_shift) samples */
   uint32_t *tile_next;         /* [n_tiles] chunks handed out so far (zero at launch)                       */
+  uint32_t *open_groups;       /* [ceil(n_tiles / 64)] tiles of the group that still have chunks            */
   int32_t n_tiles;             /* n_local_chunks * 16                                                       */
   int32_t chunk_shift;         /* log2 samples per chunk                                                    */
-  int32_t n_chunks_tile;       /* 8 rows x ceil(samples of this launch / samples per chunk)                 */
+  int32_t n_chunks_tile;       /* units per tile: 8 rows x n_sample_blocks x 4 pixel pairs                  */
+  int32_t n_sample_blocks;     /* ceil(samples of this launch / samples per unit)                           */
+  int32_t drain_thresh;        /* lanes waiting for S that trigger it once the wave's tile is exhausted     */
+  int32_t grab_max;            /* units a wave takes per atomic while its tile has plenty left (1, 2 or 4)   */
 } RT_KParams;
 
 #endif /* RT_DEVICE_H */

@@ -330,7 +330,8 @@ __device__ __forceinline__ rt_v3 texel_rgb(uint32_t t) {
                     (float)(int)((t >> 16) & 0xFFu) * k);
 }
 
-__device__ __forceinline__ rt_v3 tex_bilinear(const RT_KParams &P, int tex, float tx, float ty) {
+template <class PT>
+__device__ __forceinline__ rt_v3 tex_bilinear(const PT &P, int tex, float tx, float ty) {
   RT_DTexture T = P.textures[tex];
   if (tx < 0) tx += (float)(-(int)tx + 1);
   if (ty < 0) ty += (float)(-(int)ty + 1);
@@ -356,7 +357,8 @@ __device__ __forceinline__ rt_v3 tex_bilinear(const RT_KParams &P, int tex, floa
 }
 
 // driver.c:95-104
-__device__ __forceinline__ rt_v3 background_lookup(const RT_KParams &P, rt_v3 dir) {
+template <class PT>
+__device__ __forceinline__ rt_v3 background_lookup(const PT &P, rt_v3 dir) {
   float inv_pi = 1.0f / RT_PI;
   float inv_two_pi = 1.0f / (2.0f * RT_PI);
   float u = 0.5f + rt_atan2f(dir.z, dir.x) * inv_two_pi;
@@ -479,7 +481,8 @@ struct ShadeIn {
 };
 
 // driver.c:129-153
-__device__ __forceinline__ rt_v3 normal_map(const RT_KParams &P, int tex, float strength, const ShadeIn &in) {
+template <class PT>
+__device__ __forceinline__ rt_v3 normal_map(const PT &P, int tex, float strength, const ShadeIn &in) {
   rt_v3 normal = in.normal;
   if (tex >= 0) {
     rt_v3 v = tex_bilinear(P, tex, in.uvx, in.uvy);
@@ -495,7 +498,8 @@ __device__ __forceinline__ rt_v3 normal_map(const RT_KParams &P, int tex, float 
 }
 
 // disney_shader_proc driver.c:350-409 / debug_shader_proc :411-418 on material `mat`
-__device__ __forceinline__ void shade(const RT_KParams &P, int mat, const ShadeIn &in, uint32_t &rng,
+template <class PT>
+__device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, uint32_t &rng,
                                       rt_v3 &out_dir, rt_v3 &tint, rt_v3 &emission, bool &terminate,
                                       LaneCounters &cn) {
   const float *mb = P.mats + (size_t)mat * 20;
@@ -569,7 +573,8 @@ __device__ __forceinline__ void shade(const RT_KParams &P, int mat, const ShadeI
 
 // ---------------------------------------------------------------------------------
 // primary ray of (x, y, sample): raytracer.c:641-694 with exact 1/sqrt
-__device__ __forceinline__ void primary_ray(const RT_KParams &P, int x, int y, int sample, rt_v3 &o, rt_v3 &d) {
+template <class PT>
+__device__ __forceinline__ void primary_ray(const PT &P, int x, int y, int sample, rt_v3 &o, rt_v3 &d) {
   // 1/width, 1/height, width/height (raytracer.c:615-617) are frame constants: the host computes the same
   // three fp32 divisions once (rt_api.cpp) instead of every lane for every path
   float inv_width = P.inv_width;
@@ -605,7 +610,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // One accepted closest hit -> pass-through or material evaluation and the next ray of the path
 // (raytracer.c:515-552).  Returns true when the path ended (radiance holds its value).
-__device__ __forceinline__ bool shade_hit(const RT_KParams &P, const HitRec &hit, rt_v3 &org, rt_v3 &dir,
+template <class PT>
+__device__ __forceinline__ bool shade_hit(const PT &P, const HitRec &hit, rt_v3 &org, rt_v3 &dir,
                                           rt_v3 &tint, rt_v3 &emis, uint32_t &rng, int &bounce,
                                           LaneCounters &cn, rt_v3 &radiance) {
   bool done = false;
@@ -1136,14 +1142,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // The tile-stream path kernel (default).  Same blocks and the same per-lane arithmetic as rt_path_kernel_sched;
 // what changes is where the work comes from and how the loop is cut:
 //
-//  * A wave OWNS an 8x8-pixel tile (taken from the head counter, expensive tiles first) and pulls CHUNKS of it --
-//    one row of 8 pixels x 2^chunk_shift samples -- from the tile's own counter `tile_next[tile]` until the tile is
-//    exhausted.  Lanes whose path ended are refilled across chunk boundaries, so there is no end-of-item drain
+//  * A wave OWNS an 8x8-pixel tile (taken from the head counter, expensive tiles first) and pulls UNITS of it --
+//    2 pixels x 2^chunk_shift samples, four (one tile row) per atomic while the tile has plenty left -- from the tile's
+//    own counter `tile_next[tile]` until the tile is exhausted.  Lanes whose path ended are refilled across chunk boundaries, so there is no end-of-item drain
 //    between chunks (the scheduled kernel drains the wave at the end of every item, ~40 us each); the wave drains
 //    once per TILE.  Chunks are pixel-major, so the 64 lanes still sit on two or three pixels (coherent nodes,
 //    leaves and texels) whatever the chunk size.
-//  * When the head counter runs dry a wave JOINS a tile that still has chunks (scan of the most recently claimed
-//    tiles with agent-scope loads) and pulls from the same counter: the tail of a launch is balanced at chunk
+//  * When the head counter runs dry a wave JOINS a tile that still has chunks (two-level scan with agent-scope
+//    loads: `open_groups[g]` counts the open tiles of every group of 64) and pulls from the same counter: the tail of a launch is balanced at chunk
 //    granularity (256 paths) even when a rank of the 8-GPU partition has fewer tiles than the chip has waves.
 //    Every chunk is handed out exactly once by an atomic; radiance sums are order-free integers, so results do
 //    not depend on who traced what.  Owners always finish their tile, so a joiner may give up at any time:
@@ -1151,8 +1157,32 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 //  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
-#define RT_STEAL_WINDOW 4096      // most recently claimed tiles a joining wave looks at
-#define RT_STEAL_TRIES  16        // failed joins before a wave retires
+#define RT_STEAL_TRIES  16        // failed joins in a row before a wave retires
+
+// Kernel arguments that are only needed outside the traversal loop (camera, frame and tile bookkeeping, material
+// tables) are read from the kernarg segment WHERE they are used, through a pointer the compiler cannot see through:
+// kept live across the traversal loop they cost ~50 scalar registers, and the spills of those (to VGPR lanes, then
+// VGPRs to scratch) were measured at +3 % frame time.  A scalar load per use in the shade / regenerate block is free
+// by comparison (that block runs once per ~4.6 traversal blocks and is several hundred instructions long).
+typedef const RT_KParams __attribute__((address_space(4))) *RT_KArgs;
+__device__ __forceinline__ RT_KArgs cold_args() {
+  RT_KArgs p = (RT_KArgs)__builtin_amdgcn_kernarg_segment_ptr();      // the RT_KParams block is the kernel's only argument
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+struct ShadeParams {            // what shade_hit / background_lookup read (same field names as RT_KParams)
+  const float *tris, *mats;
+  const RT_DTexture *textures;
+  const uint32_t *texels;
+  int32_t bg_texture, max_bounces;
+};
+
+struct PrimaryParams {          // what primary_ray reads
+  float cam[3][4];
+  float focal_length, inv_width, inv_height, aspect;
+};
+
 
 template <int WAVES, bool LDSN, int MIN_WAVES_PER_SIMD = 1>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel_stream(RT_KParams P) {
@@ -1181,12 +1211,16 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 
   // wave-level counters (scalar registers)
   uint32_t w_paths = 0, w_rays = 0, w_nodes = 0, w_leaves = 0, w_shades = 0, w_bgs = 0, w_tex = 0;
+  const unsigned long long t_wave_start = cold_args()->wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // RT_WAVE_TIMES only
+  uint32_t n_tiles_done = 0;
+  unsigned long long t_last_grab = 0ull;
 
   const int shift = P.chunk_shift;                 // samples per chunk = 1 << shift
-  const int chunk_paths = 8 << shift;              // 8 pixels of one tile row
-  const uint32_t n_chunks_tile = (uint32_t)P.n_chunks_tile;
+  const int unit_paths = 2 << shift;               // a unit = 2 neighbouring pixels x (1 << shift) samples
+  const uint32_t n_chunks_tile = (uint32_t)P.n_chunks_tile;      // units per tile: 8 rows x sample blocks x 4 pixel pairs
   const int leaf_level = P.depth - 1;
   const int thresh = P.sched_thresh;
+  const int drain_thresh = P.drain_thresh;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int wave_id = (int)blockIdx.x * WAVES + wave;
 
@@ -1197,51 +1231,115 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     // ---------------- take a tile: own one from the queue, or join one that still has chunks ----------------
     int tile_idx = -1;
     if (queue_open) {
+      RT_KArgs A = cold_args();
       uint32_t pos = 0;
-      if (lane == 0) pos = atomicAdd(P.work_head, 1u);
+      if (lane == 0) pos = atomicAdd(A->work_head, 1u);
       pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-      if (pos < (uint32_t)P.n_tiles) tile_idx = P.order ? (int)P.order[pos] : (int)pos;
+      const uint32_t *order = A->order;
+      if (pos < (uint32_t)A->n_tiles) tile_idx = order ? (int)order[pos] : (int)pos;
       else queue_open = false;
     }
     if (tile_idx < 0) {
       if (steal_tries >= RT_STEAL_TRIES) break;
       steal_tries += 1;
-      // tiles are claimed in queue order, so the ones still in progress are the last ones claimed
-      const int window = P.n_tiles < RT_STEAL_WINDOW ? P.n_tiles : RT_STEAL_WINDOW;
-      const int rounds = (window + 63) >> 6;
-      const int start = (int)(((uint32_t)wave_id * 2654435761u + (uint32_t)steal_tries * 40503u) >> 8) % rounds;
-      for (int i = 0; i < rounds && tile_idx < 0; i++) {
-        int r = start + i;
-        if (r >= rounds) r -= rounds;
-        int off = r * 64 + lane;
-        int cand = -1;
-        uint32_t taken = 0xFFFFFFFFu;
-        if (off < window) {
-          int pos = P.n_tiles - 1 - off;
-          cand = P.order ? (int)P.order[pos] : pos;
-          taken = __hip_atomic_load(&P.tile_next[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned long long open = __ballot(taken < n_chunks_tile);
-        if (open) {
-          // one of the open tiles of this group, not always the first: joiners spread over them
-          int nth = (int)(((uint32_t)wave_id >> 2) % (uint32_t)__popcll(open));
-          unsigned long long m = open;
+      // two-level scan with agent-scope loads: groups of 64 tiles that still have an open tile (open_groups[g] > 0),
+      // then the tiles of one such group.  Start positions differ per wave so that joiners spread over the open tiles.
+      RT_KArgs A = cold_args();
+      const int n_tiles = A->n_tiles;
+      const uint32_t *open_groups = A->open_groups, *tile_next = A->tile_next;
+      const int n_groups = (n_tiles + 63) >> 6;
+      const int g_rounds = (n_groups + 63) >> 6;
+      const uint32_t hsh = ((uint32_t)wave_id * 2654435761u + (uint32_t)steal_tries * 40503u) >> 8;
+      const int g_start = (int)(hsh % (uint32_t)g_rounds);
+      for (int i = 0; i < g_rounds && tile_idx < 0; i++) {
+        int r = g_start + i;
+        if (r >= g_rounds) r -= g_rounds;
+        int g = r * 64 + lane;
+        uint32_t n_open = 0;
+        if (g < n_groups) n_open = __hip_atomic_load(&open_groups[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long gm = __ballot(n_open != 0u);
+        while (gm && tile_idx < 0) {
+          int nth = (int)((hsh >> 6) % (uint32_t)__popcll(gm));
+          unsigned long long m = gm;
           for (int k = 0; k < nth; k++) m &= m - 1ull;
-          int src = (int)__builtin_ctzll(m);
-          tile_idx = __builtin_amdgcn_readlane(cand, src);
+          int gl = (int)__builtin_ctzll(m);
+          gm &= ~(1ull << gl);
+          int cand = (r * 64 + gl) * 64 + lane;
+          uint32_t taken = 0xFFFFFFFFu;
+          if (cand < n_tiles) taken = __hip_atomic_load(&tile_next[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned long long open = __ballot(taken < n_chunks_tile);
+          if (open) {
+            int nt = (int)((hsh >> 12) % (uint32_t)__popcll(open));
+            unsigned long long mm = open;
+            for (int k = 0; k < nt; k++) mm &= mm - 1ull;
+            tile_idx = cand - lane + (int)__builtin_ctzll(mm);
+          }
         }
       }
       if (tile_idx < 0) break;                      // nothing left to join
     }
 
-    const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
-    const int chunk = P.local_chunks[lchunk];
-    const int tile_x0 = (chunk % P.chunks_x) * 32 + (sub & 3) * 8;
-    const int tile_y0 = (chunk / P.chunks_x) * 32 + (sub >> 2) * 8;
-    if (tile_x0 >= P.width || tile_y0 >= P.height) {
-      // tile entirely outside the image: mark it exhausted so that no wave tries to join it
-      if (lane == 0) atomicMax(&P.tile_next[tile_idx], n_chunks_tile);
-      continue;
+    int tile_x0, tile_y0;
+    {
+      RT_KArgs A = cold_args();
+      const int lchunk = tile_idx >> 4, sub = tile_idx & 15;
+      const int chunk = A->local_chunks[lchunk];
+      const int chunks_x = A->chunks_x;
+      tile_x0 = (chunk % chunks_x) * 32 + (sub & 3) * 8;
+      tile_y0 = (chunk / chunks_x) * 32 + (sub >> 2) * 8;
+      if (tile_x0 >= A->width || tile_y0 >= A->height) {
+        // tile entirely outside the image: mark it exhausted (once) so that no wave tries to join it
+        if (lane == 0) {
+          uint32_t old = atomicMax(&A->tile_next[tile_idx], n_chunks_tile);
+          if (old < n_chunks_tile) atomicSub(&A->open_groups[tile_idx >> 6], 1u);
+        }
+        continue;
+      }
+    }
+    // ---- can a camera ray of this tile touch the scene at all? ----
+    // The primary rays of the tile share the origin and lie inside the pyramid through the corners of the tile's pixel
+    // footprint.  If every populated child box of the ROOT lies outside one of the pyramid's four side planes -- by a
+    // relative margin of 1e-3, a thousand times the rounding error of the slab test -- then ray_aabbs_hit_8 returns
+    // "no candidate" for every one of them (raytracer.c:190-230, :459-472): the ray costs one node visit and goes to the
+    // environment.  Such rays skip the root block here and are counted as that one visit.  (Lanes 0..7 test one child
+    // box each; only rays with finite reciprocal direction take the shortcut, see ray_setup.)
+    bool tile_root_miss = false;
+    if (leaf_level >= 0) {
+      RT_KArgs A = cold_args();
+      const float m = 0.05f;                                   // footprint margin in pixels
+      const float ux0 = ((float)tile_x0 - 0.5f - m) * 2.0f * A->inv_width - 1.0f;
+      const float ux1 = ((float)tile_x0 + 7.5f + m) * 2.0f * A->inv_width - 1.0f;
+      const float uy0 = ((float)tile_y0 - 0.5f - m) * 2.0f * A->inv_height - 1.0f;
+      const float uy1 = ((float)tile_y0 + 7.5f + m) * 2.0f * A->inv_height - 1.0f;
+      const float asp = A->aspect, fl = A->focal_length;
+      rt_v3 c[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float cx = ((q == 1 || q == 2) ? ux1 : ux0) * asp, cy = -((q >= 2) ? uy1 : uy0), cz = -fl;
+        c[q] = rt_v3_make(A->cam[0][0] * cx + A->cam[0][1] * cy + A->cam[0][2] * cz,
+                          A->cam[1][0] * cx + A->cam[1][1] * cy + A->cam[1][2] * cz,
+                          A->cam[2][0] * cx + A->cam[2][1] * cy + A->cam[2][2] * cz);
+      }
+      const rt_v3 o = rt_v3_make(A->cam[0][3], A->cam[1][3], A->cam[2][3]);
+      bool may_hit = false;
+      if (lane < 8) {
+        const float *nb = P.nodes + lane;                      // child `lane` of node 0: rows are 8 floats apart
+        rt_v3 lo = rt_v3_make(nb[0] - o.x, nb[8] - o.y, nb[16] - o.z);
+        rt_v3 hi = rt_v3_make(nb[24] - o.x, nb[32] - o.y, nb[40] - o.z);
+        const bool empty = nb[0] == 0.0f && nb[8] == 0.0f && nb[16] == 0.0f && nb[24] == 0.0f && nb[32] == 0.0f && nb[40] == 0.0f;
+        bool outside = empty;                                  // the all-zero box of an unpopulated child never hits
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          rt_v3 n = rt_v3_cross(c[q], c[(q + 1) & 3]);
+          if (rt_v3_dot(n, c[(q + 2) & 3]) > 0.0f) n = rt_v3_scale(n, -1.0f);      // outward: the opposite corner is inside
+          float lox = n.x * lo.x, hix = n.x * hi.x, loy = n.y * lo.y, hiy = n.y * hi.y, loz = n.z * lo.z, hiz = n.z * hi.z;
+          float nearest = fminf(lox, hix) + fminf(loy, hiy) + fminf(loz, hiz);     // smallest n . (p - o) over the box
+          float extent = fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz));
+          if (nearest > 1e-3f * extent) outside = true;        // (NaN compares false: not outside)
+        }
+        may_hit = !outside;
+      }
+      tile_root_miss = __ballot(may_hit) == 0ull;
     }
     const uint32_t rays_before = w_rays;
 
@@ -1257,9 +1355,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     HitRec hit;
     hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
 
-    // current chunk of the tile (wave-uniform): paths [c_next, c_end) of row c_y, samples from c_s0
+    // The tile hands out UNITS (2 pixels x one block of samples = 64 paths at 32 samples: one wave-load, lanes on two
+    // pixels).  A wave grabs 4 consecutive units (one row of the tile for one sample block) per atomic while the tile
+    // has plenty left, 2 and then 1 towards its end: the last units of a launch are spread over the waves that
+    // join the tile instead of keeping one wave busy for 256 paths.  Current unit (wave-uniform): paths
+    // [c_next, c_end) at pixels (c_x0 .. c_x0 + 1, c_y), samples from c_s0.
     bool tile_open = true;
-    int  c_next = 0, c_end = 0, c_y = 0, c_row = 0, c_s0 = 0;
+    int  c_next = 0, c_end = 0, c_x0 = 0, c_y = 0, c_pix0 = 0, c_s0 = 0;
+    uint32_t u_cur = 0, u_end = 0, grab = queue_open ? (uint32_t)cold_args()->grab_max : 1u;
     bool took_any = false;
 
     for (;;) {
@@ -1267,15 +1370,19 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       {
         LaneCounters cn;
         cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
-        bool  done = false, start = false;
+        bool  done = false, start = false, fresh = false;
         rt_v3 radiance = rt_v3_make(0, 0, 0);
         rt_v3 org = ray.o, dir = ray.d;
+        RT_KArgs A = cold_args();
+        ShadeParams SP;
+        SP.tris = A->tris; SP.mats = A->mats; SP.textures = A->textures; SP.texels = A->texels;
+        SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
         if (phase == PH_HIT) {
-          done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
+          done = shade_hit(SP, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
           start = !done;
         } else if (phase == PH_MISS) {
           cn.bgs = 1;
-          rt_v3 bg = background_lookup(P, dir);
+          rt_v3 bg = background_lookup(SP, dir);
           radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
           done = true;
         }
@@ -1294,18 +1401,40 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           unsigned long long need = __ballot(phase == PH_NEED);
           bool got = false;
           int  gx = 0, gy = 0, gs = 0, gp = 0;
+          const int width = A->width, sample_end = A->sample_end;
           while (need) {
             if (c_next >= c_end) {
-              uint32_t c = 0;
-              if (lane == 0) c = atomicAdd(&P.tile_next[tile_idx], 1u);
-              c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-              if (c >= n_chunks_tile) { tile_open = false; break; }
-              took_any = true;
-              c_row = (int)(c & 7u);
-              c_y = tile_y0 + c_row;
-              c_s0 = P.sample_first + (int)((c >> 3) << shift);
+              if (u_cur + 1u < u_end) {
+                u_cur += 1u;
+              } else {
+                uint32_t u0 = 0;
+                if (lane == 0) u0 = atomicAdd(&A->tile_next[tile_idx], grab);
+                u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)u0);
+                if (u0 >= n_chunks_tile) { tile_open = false; break; }
+                u_cur = u0;
+                u_end = u0 + grab < n_chunks_tile ? u0 + grab : n_chunks_tile;
+                // exactly one wave receives the tile's last unit: it closes the tile in the group summary
+                if (u_end == n_chunks_tile && lane == 0) atomicSub(&A->open_groups[tile_idx >> 6], 1u);
+                if (t_wave_start) t_last_grab = __builtin_amdgcn_s_memrealtime();
+                // next grab: `grab_max` units (4 = one tile row) while the tile has plenty left, fewer towards its end.
+                // (A launch-wide count of the remaining units would be the better guide, but a counter that every grab
+                // updates -- one address or 64 shards of one line -- made the frame 2x slower: measured, removed.)
+                const uint32_t left = n_chunks_tile - u_end;
+                const uint32_t gmax = (uint32_t)A->grab_max;
+                grab = left >= 8u * gmax ? gmax : (left >= 8u && gmax >= 2u ? 2u : 1u);
+                took_any = true;
+              }
+              // unit u -> (row, sample block, pixel pair): all sample blocks of a row before the next row, so a
+              // pixel's texture / geometry footprint is touched in one burst
+              const uint32_t grp = u_cur >> 2, pair = u_cur & 3u;
+              const uint32_t n_sb = (uint32_t)A->n_sample_blocks;
+              const uint32_t row = grp / n_sb, sb = grp - row * n_sb;
+              c_x0 = tile_x0 + (int)pair * 2;
+              c_y = tile_y0 + (int)row;
+              c_pix0 = (int)row * 8 + (int)pair * 2;
+              c_s0 = A->sample_first + (int)(sb << shift);
               c_next = 0;
-              c_end = (c_y < P.height) ? chunk_paths : 0;      // a row below the image has no paths
+              c_end = (c_y < A->height && c_x0 < width) ? unit_paths : 0;      // units outside the image have no paths
               continue;
             }
             const int n_need = (int)__popcll(need);
@@ -1318,10 +1447,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
               int k = c_next + rank;
               int px = k >> shift;
               int sm = c_s0 + (k & ((1 << shift) - 1));
-              int x = tile_x0 + px;
-              if (x < P.width && sm < P.sample_end) {
+              int x = c_x0 + px;
+              if (x < width && sm < sample_end) {
                 valid = true;
-                if (P.max_bounces > 0) { got = true; gx = x; gy = c_y; gs = sm; gp = c_row * 8 + px; }
+                if (SP.max_bounces > 0) { got = true; gx = x; gy = c_y; gs = sm; gp = c_pix0 + px; }
                 // max_bounces == 0: the path exists and is black (the loop of raytracer.c:512 runs zero times)
               }
             }
@@ -1332,13 +1461,21 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           if (got) {
             pix = gp;
             bounce = 0;
-            rng = rt_path_seed(P.seed, (uint32_t)(gx + gy * P.width), (uint32_t)gs);
-            primary_ray(P, gx, gy, gs, org, dir);
+            rng = rt_path_seed(A->seed, (uint32_t)(gx + gy * width), (uint32_t)gs);
+            PrimaryParams PP;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+              for (int j = 0; j < 4; j++) PP.cam[i][j] = A->cam[i][j];
+            PP.focal_length = A->focal_length; PP.inv_width = A->inv_width; PP.inv_height = A->inv_height; PP.aspect = A->aspect;
+            primary_ray(PP, gx, gy, gs, org, dir);
             tint = rt_v3_make(1, 1, 1);
             emis = rt_v3_make(0, 0, 0);
             start = true;
+            fresh = true;
           }
         }
+        bool skip_root = false;
         if (start) {                      // a new ray: traversal starts at the root (or at leaf group 0)
           ray_setup(ray, org, dir);
           hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
@@ -1347,14 +1484,19 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           cur = 0;
           level = -1;
           node = 0;
-          child = (P.depth > 0) ? 0 : P.last_row_offset;
-          phase = (P.depth > 0) ? PH_NODE : PH_LEAF;
+          child = (leaf_level >= 0) ? 0 : P.last_row_offset;
+          phase = (leaf_level >= 0) ? PH_NODE : PH_LEAF;
+          // camera ray of a tile that cannot touch the scene: its one node visit finds no candidate (see tile_root_miss)
+          skip_root = fresh && tile_root_miss && ray.fast;
+          if (skip_root) phase = PH_MISS;
         }
         w_rays += (uint32_t)__popcll(__ballot(start));
+        w_nodes += (uint32_t)__popcll(__ballot(skip_root));
       }
 
       const int n_trav0 = (int)__popcll(__ballot(phase == PH_NODE || phase == PH_LEAF));
       if (n_trav0 == 0) {
+        if (__any(phase == PH_MISS)) continue;   // camera rays that skipped the root: straight to the environment
         if (!tile_open) break;            // every path of the tile that this wave took has ended
         continue;                         // (nothing started, e.g. pixels outside the image: pull more)
       }
@@ -1363,7 +1505,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       for (;;) {
         const int nN = (int)__popcll(__ballot(phase == PH_NODE));
         const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
-        if (nN + nL == 0 || n_trav0 - (nN + nL) >= thresh) break;
+        // while the tile still hands out paths, wait until `thresh` lanes want the S block (dense shading); once it is
+        // exhausted nothing refills the lanes, and what matters is the latency of the remaining paths' bounce chains:
+        // shade as soon as `drain_thresh` lanes wait
+        if (nN + nL == 0 || n_trav0 - (nN + nL) >= (tile_open ? thresh : drain_thresh)) break;
 
         if (nL >= nN) {
           // ----- LEAF -----
@@ -1447,25 +1592,36 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       acc[lane * 3 + 0] = 0ull;
       acc[lane * 3 + 1] = 0ull;
       acc[lane * 3 + 2] = 0ull;
-      if (x < P.width && y < P.height && (r | g | b) != 0ull) {
-        unsigned long long *dst = P.accum + ((size_t)y * P.width + x) * 3;
+      RT_KArgs A = cold_args();
+      const int width = A->width;
+      if (x < width && y < A->height && (r | g | b) != 0ull) {
+        unsigned long long *dst = A->accum + ((size_t)y * width + x) * 3;
         atomicAdd(dst + 0, r);
         atomicAdd(dst + 1, g);
         atomicAdd(dst + 2, b);
       }
-      if (P.tile_cost && lane == 0) atomicAdd(&P.tile_cost[tile_idx], w_rays - rays_before);
+      uint32_t *tile_cost = A->tile_cost;
+      if (tile_cost && lane == 0) atomicAdd(&tile_cost[tile_idx], w_rays - rays_before);
       steal_tries = 0;                    // joined (or owned) a tile that had work: keep looking for more
+      n_tiles_done += 1;
     }
+  }
+  RT_KArgs A = cold_args();
+  unsigned long long *wave_times = A->wave_times, *counters = A->counters;
+  if (wave_times && lane == 0 && wave_id < 65536) {
+    wave_times[wave_id * 3 + 0] = t_wave_start;
+    wave_times[wave_id * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+    wave_times[wave_id * 3 + 2] = ((t_last_grab - t_wave_start) << 16) | (n_tiles_done & 0xFFFFu);
   }
 
   if (lane == 0) {
-    atomicAdd(P.counters + CNT_PATHS, (unsigned long long)w_paths);
-    atomicAdd(P.counters + CNT_RAYS, (unsigned long long)w_rays);
-    atomicAdd(P.counters + CNT_NODES, (unsigned long long)w_nodes);
-    atomicAdd(P.counters + CNT_LEAVES, (unsigned long long)w_leaves);
-    atomicAdd(P.counters + CNT_SHADES, (unsigned long long)w_shades);
-    atomicAdd(P.counters + CNT_BG, (unsigned long long)w_bgs);
-    atomicAdd(P.counters + CNT_TEXTURED, (unsigned long long)w_tex);
+    atomicAdd(counters + CNT_PATHS, (unsigned long long)w_paths);
+    atomicAdd(counters + CNT_RAYS, (unsigned long long)w_rays);
+    atomicAdd(counters + CNT_NODES, (unsigned long long)w_nodes);
+    atomicAdd(counters + CNT_LEAVES, (unsigned long long)w_leaves);
+    atomicAdd(counters + CNT_SHADES, (unsigned long long)w_shades);
+    atomicAdd(counters + CNT_BG, (unsigned long long)w_bgs);
+    atomicAdd(counters + CNT_TEXTURED, (unsigned long long)w_tex);
   }
 }
 
@@ -1780,6 +1936,22 @@ static int launch_sched(const RT_KParams *P, int n_waves, int smem_bytes, hipStr
   }
   hipLaunchKernelGGL((rt_path_kernel_sched<WAVES, LDSN, STATS, MINW>), dim3((n_waves + WAVES - 1) / WAVES), dim3(WAVES * 64),
                      smem_bytes, stream, *P);
+  return (int)hipGetLastError();
+}
+
+// per launch: no chunk handed out yet; every group of 64 tiles is open
+__global__ void rt_stream_init_kernel(int n_tiles, uint32_t *tile_next, uint32_t *open_groups) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_tiles) tile_next[i] = 0u;
+  int n_groups = (n_tiles + 63) >> 6;
+  if (i < n_groups) {
+    int left = n_tiles - i * 64;
+    open_groups[i] = (uint32_t)(left < 64 ? left : 64);
+  }
+}
+
+extern "C" int rt_launch_stream_init(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_stream_init_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, n_tiles, tile_next, open_groups);
   return (int)hipGetLastError();
 }
 
