@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--save", default="", help="write the last frame as PNG (rank 0)")
+    ap.add_argument("--no-bvh-compare", action="store_true",
+                    help="skip the side measurement of the opt-in SAH builder (config.bvh.sah)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: ranks rendezvous (gloo), exchange an empty tile buffer, rank 0 prints a "
                          "stub line -- covers the launcher and the N-rank plumbing on a CPU-only machine")
@@ -224,6 +226,51 @@ def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_na
                            "note": "issue_frac_profiled_clock = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): "
                                    "issue slots at the clock of the profiled launch; useful = issue x active lanes"}
     return out
+
+
+def bvh_compare(rt, abi, args, cfg, image_ref, steps=3):
+    """Side measurement for config.bvh: the same frame on a scene built by the opt-in scene_init_sah() (same layout,
+    tighter boxes).  The headline stays on the reference's split (scene.c:311-414); GPU == oracle parity is untouched
+    because both traverse whatever Scene they are given.  Returns node / leaf visits per ray, Mray/s and the number of
+    pixels that differ from the reference-split image (only exact-distance ties may)."""
+    import numpy as np
+    import torch
+    from raytracing_c_amd.configs import load_config
+    hs, _ = load_config(args.config, builder="sah")
+    w, h, s, b = cfg["width"], cfg["height"], cfg["samples"], cfg["max_bounces"]
+    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    if not d:
+        return {"error": rt.last_error()}
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        accum = torch.zeros((h, w, 3), dtype=torch.int64, device=dev)
+        image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        params = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, 0, 1, args.slab, 0)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def frame():
+            accum.zero_()
+            if rt.lib.rt_render_accumulate(d, C.byref(params), accum.data_ptr(), stream) != 0:
+                raise RuntimeError(rt.last_error())
+            if rt.lib.rt_resolve(C.byref(params), accum.data_ptr(), None, image.data_ptr(), None, stream) != 0:
+                raise RuntimeError(rt.last_error())
+
+        frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        cnt = rt.render.get_counters()
+        differing = int((image.cpu().numpy() != image_ref).any(axis=2).sum()) if image_ref is not None else None
+        return {"builder": "scene_init_sah (opt-in; same implicit 8-ary layout)", "mray_per_s": cnt.rays / dt / 1e6,
+                "ms_per_step": dt * 1e3, "node_visits_per_ray": cnt.node_visits / max(cnt.rays, 1),
+                "leaf_visits_per_ray": cnt.leaf_visits / max(cnt.rays, 1), "rays_per_frame": cnt.rays,
+                "pixels_differing_from_reference_split": differing, "pixels": w * h,
+                "build_ms": hs.scene_init_seconds * 1e3}
+    finally:
+        rt.lib.rt_scene_release(d)
 
 
 def dry_run(args, world, rank):
@@ -418,7 +465,7 @@ def main():
         elif args.config == "helmet4k" and (w, h, s, b) == (3840, 2160, 1024, 16):
             workload += " (BASELINE.json configs[4])"
         prof = measured_profile(workload) if world == 1 else None
-        variant = os.environ.get("RT_KERNEL", "default")
+        variant = os.environ.get("RT_KERNEL", "5 = rt_path_kernel_stream<16, true>, the default")
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
@@ -426,7 +473,10 @@ def main():
             "config": {"workload": workload,
                        "scene": "assets/helmet.glb = self-contained models/helmet.gltf; procedural 2048x1024 "
                                 "equirect background (background.png is a missing blob); seed 0x1234ABCD",
-                       "bvh": "scene_init (the reference's fixed-capacity split, scene.c:311-414)",
+                       "bvh": {"headline": "scene_init (the reference's fixed-capacity split, scene.c:311-414)",
+                               "reference": {"mray_per_s": mrays, "node_visits_per_ray": tot.node_visits / max(rays, 1),
+                                             "leaf_visits_per_ray": tot.leaf_visits / max(rays, 1),
+                                             "build_ms": hs.scene_init_seconds * 1e3}},
                        "partition": f"32x32 chunks dealt to {world} GPU(s) by the (cx + B cy) mod world lattice, "
                                     f"{'RCCL' if backend == 'nccl' else backend} gather of u8 tiles to rank 0"
                                     if world > 1 else "single GPU"},
@@ -441,6 +491,8 @@ def main():
             "roofline": roofline_block(tot, rays_per_launch, last_ms, n_launches.value, prof,
                                        f"rt_path_kernel (RT_KERNEL={variant})"),
         }
+        if world == 1 and not args.no_bvh_compare:
+            out["config"]["bvh"]["sah"] = bvh_compare(rt, abi, args, cfg, host_images[(frame_no[0] - 1) & 1].numpy())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)
         if args.save:
