@@ -12,7 +12,7 @@ i=0
 for C in "$@"; do
   i=$((i+1))
   D=$OUT/pmcraw_${TAG}_$i
-  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $D -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 0 ${BENCH_ARGS:-} > $D.json 2> $D.err || echo "pass $i failed: $C" >> $OUT/pmc_${TAG}.txt
+  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $D -- python3 $R/bench.py --no-cpu-baseline --no-bvh-compare --steps 1 --warmup 0 ${BENCH_ARGS:-} > $D.json 2> $D.err || echo "pass $i failed: $C" >> $OUT/pmc_${TAG}.txt
   python3 - "$D" >> $OUT/pmc_${TAG}.txt <<'PY'
 import csv,glob,sys,collections
 agg=collections.OrderedDict()
