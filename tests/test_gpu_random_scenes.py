@@ -102,3 +102,63 @@ def test_duplicate_triangles_resolve_ties_like_the_oracle(oracle):
         same = np.nonzero((soa == soa[t]).all(axis=1))[0]
         dup += len(same) > 1
     assert dup >= 2
+
+
+def _look_at(eye, target, up=(0.0, 1.0, 0.0)):
+    """view_matrix of driver.c:765 convention: columns = camera x, y, z axes in world space (camera looks down -z), translation."""
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, up)
+    if np.linalg.norm(r) < 1e-6:
+        r = np.cross(f, (1.0, 0.0, 0.0))
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = r, u, -f, eye
+    return m
+
+
+@pytest.mark.parametrize("name", ["spheres", "tower", "helmet"])
+def test_tile_frustum_root_culling_never_changes_a_ray(oracle, name):
+    """The tile-stream kernel lets camera rays skip the root block when the tile's pixel pyramid misses every child
+    box of the root (rt_kernels.hip, tile_misses_root) and counts them as the one node visit they would have cost.
+    That is an argument by margin, so it gets its own fuzz: cameras far away, close up, INSIDE the scene bounds, looking
+    away from the scene, grazing the bounds so that tile pyramids pass within a hair of the root's boxes, narrow and wide
+    fields of view, frames whose last tiles are ragged.  Radiance sums and all seven counters must equal the oracle's
+    (node_visits is the sensitive one: a wrongly skipped ray would still count 1 but lose its later visits; a wrongly
+    kept one costs nothing)."""
+    import raytracing_c_amd as rt
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    hs, _ = load_config(name)
+    nodes = hs.nodes_array()[0]                                   # root: (6, 8) child boxes
+    used = np.any(nodes != 0, axis=0)
+    lo, hi = nodes[0:3][:, used].min(axis=1), nodes[3:6][:, used].max(axis=1)
+    centre, ext = (lo + hi) / 2, (hi - lo) / 2
+    rng = np.random.default_rng({"spheres": 21, "tower": 22, "helmet": 23}[name])
+    views = []
+    for _ in range(5):                                            # anywhere around, looking roughly at the scene
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        eye = centre + d * ext.max() * rng.uniform(1.5, 6.0)
+        views.append((eye, centre + rng.normal(size=3) * ext * 0.8, rng.uniform(0.3, 1.6)))
+    for _ in range(3):                                            # grazing: aim just past a corner of the bounds
+        corner = centre + ext * rng.choice([-1.0, 1.0], 3)
+        eye = centre + (corner - centre) * rng.uniform(2.0, 4.0) + rng.normal(size=3) * 0.3 * ext
+        views.append((eye, corner + (corner - centre) * rng.uniform(0.01, 0.3), rng.uniform(0.2, 0.8)))
+    views.append((centre + rng.uniform(-0.3, 0.3, 3) * ext, centre + rng.normal(size=3), 1.2))          # inside the bounds
+    views.append((centre + np.array([0, 0, 1.0]) * ext.max() * 3, centre + np.array([0, 0, 1.0]) * ext.max() * 9, 1.0))   # looking away
+    skipped_somewhere = False
+    for i, (eye, target, fov) in enumerate(views):
+        hs.set_camera(_look_at(eye, target), float(fov))
+        w, h, s, b = (88, 56, 2, 3) if i % 2 else (61, 43, 3, 2)
+        want = _oracle.render(hs, w, h, s, b, seed=100 + i)
+        got = rt.render_frame(hs, w, h, s, b, seed=100 + i, want_accum=True)
+        assert np.array_equal(want["accum"], got["accum"]), (name, i)
+        c = got["counters"]
+        for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+            assert want["counters"][k] == getattr(c, k), (name, i, k)
+        skipped_somewhere |= c.backgrounds > 0
+    assert skipped_somewhere
