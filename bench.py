@@ -156,7 +156,8 @@ def measured_profile(workload):
     bench.py cannot read PMC counters itself: these values are REPLAYED and labelled as such."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime):
+    # newest = last in name order (r01 < r01f < ... < r02): file times mean nothing after a fresh clone
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             t = json.load(open(f))
         except Exception:
