@@ -51,6 +51,12 @@ extern i64              rt_scene_device_bytes(RT_Device_Scene const *dscene);
  * rt_scene_upload() captures scene->camera, this replaces it. */
 extern int rt_set_camera(RT_Device_Scene *dscene, Camera const *camera);
 
+/* scene_init() (rt_scene.h, reference scene.c:416-426) with the build done by GPU kernels: fills `scene` with the SAME
+ * bytes scene_init() would -- same triangles in the same slots, same child boxes (the cut positions of the reference's
+ * split depend on counts only, so the host plans them and the GPU runs the sorts, bounds and inserts level by level;
+ * csrc/rt_build.hip).  Host memory comes from `allocator` as in scene_init.  0 on success. */
+extern int scene_init_gpu(Scene *scene, Triangle_Slice src_triangles, Allocator allocator);
+
 /* ---- rendering -------------------------------------------------------------- */
 
 typedef struct {

@@ -154,6 +154,10 @@ static inline isize bvh_n_internal_nodes(isize depth) {
  *     reading nodes[0] out of bounds (raytracer.c:451). */
 extern void scene_init(Scene *scene, Triangle_Slice src_triangles, Allocator allocator);
 
+/* The allocation half of scene_init: sets bvh.depth / last_row_offset / nodes (zeroed) and the zeroed triangle block for
+ * `n_triangles` input triangles.  false when the allocator fails. */
+extern bool rt_scene_alloc(Scene *scene, isize n_triangles, Allocator allocator);
+
 /* Opt-in quality builder (the reference has none): surface-area-heuristic build into the
  * SAME implicit 8-ary layout -- same depth, node format, leaf-group addressing -- so everything that consumes a
  * Scene (render_thread_proc, lightmap_bake, the .scene file, the CPU oracle) works on it unchanged.  Fewer

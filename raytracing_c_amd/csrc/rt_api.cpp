@@ -1183,6 +1183,29 @@ extern "C" int render(Scene *scene, Image *image, isize samples, isize max_bounc
 }
 
 // ---------------------------------------------------------------------------------
+// scene_init on the GPU (csrc/rt_build.hip): same Scene, byte for byte, as scene_init()
+
+extern "C" int rt_gpu_build(const Triangle *h_tris, long n_in, long depth, BVH_Node *h_nodes, long n_internal, float *h_block,
+                            long block_len, char *err, int err_len);
+
+extern "C" int scene_init_gpu(Scene *scene, Triangle_Slice src, Allocator allocator) {
+  if (!scene) return rt_fail("scene_init_gpu: scene is NULL");
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (ensure_device() != 0) return -1;
+  }
+  if (src.len < 0 || (src.len > 0 && !src.data)) return rt_fail("scene_init_gpu: bad triangle slice");
+  if (src.len > (isize)1 << 27) return rt_fail("scene_init_gpu: %ld triangles are too many", (long)src.len);
+  if (!rt_scene_alloc(scene, src.len, allocator)) return rt_fail("scene_init_gpu: the allocator failed");   // (drops a stale device copy)
+  char err[256] = "";
+  std::lock_guard<std::mutex> lock(g_mutex);
+  int rc = rt_gpu_build(src.data, (long)src.len, (long)scene->bvh.depth, scene->bvh.nodes.data, (long)scene->bvh.nodes.len,
+                        scene->triangles.x[0], (long)scene->triangles.len, err, (int)sizeof err);
+  if (rc != 0) return rt_fail("scene_init_gpu: %s", err);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // denoiser (reference denoiser.h / denoiser.c:131-153), SURVEY.md section 8f #3
 
 extern "C" int rt_denoise(i32 width, i32 height, void const *d_src, void *d_dst, void *stream) {

@@ -307,9 +307,12 @@ static void *build_job_run(void *arg) {
 
 /* scene.c:416-426.  Sorts a private copy of the input (the reference sorts the
  * caller's slice in place). */
-void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
+/* The allocation half of scene_init (scene.c:416-424): depth and node count from the triangle count, zeroed node array,
+ * zeroed SoA + AoS triangle block.  false (and an empty scene, which the upload refuses) when the allocator fails.
+ * Shared by scene_init, scene_init_sah and the GPU builder scene_init_gpu (rt_api.cpp). */
+bool rt_scene_alloc(Scene *scene, isize n_triangles, Allocator allocator) {
   if (rt_scene_invalidate) rt_scene_invalidate(scene);      /* a device copy of what this Scene held before is stale */
-  isize depth      = bvh_required_depth(src.len);
+  isize depth      = bvh_required_depth(n_triangles);
   isize n_internal = bvh_n_internal_nodes(depth);
   scene->bvh.depth           = depth;
   scene->bvh.last_row_offset = n_internal;
@@ -318,12 +321,18 @@ void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
   memset(&scene->triangles, 0, sizeof scene->triangles);
   if (!scene->bvh.nodes.data) {          /* allocation failed: an empty scene (len 0), which the upload refuses */
     scene->bvh.nodes.len = 0;
-    return;
+    return false;
   }
   if (!triangles_init(&scene->triangles, bvh_n_leaf_nodes(depth) * RT_BVH_WIDTH, allocator)) {
     memset(&scene->triangles, 0, sizeof scene->triangles);
-    return;
+    return false;
   }
+  return true;
+}
+
+void scene_init(Scene *scene, Triangle_Slice src, Allocator allocator) {
+  if (!rt_scene_alloc(scene, src.len, allocator)) return;
+  isize depth = scene->bvh.depth;
   if (src.len <= 0) return;
 
   isize n = src.len;
@@ -476,19 +485,8 @@ static void sah_build(Scene *scene, Triangle *tris, isize count, isize depth, BV
 }
 
 void scene_init_sah(Scene *scene, Triangle_Slice src, Allocator allocator) {
-  if (rt_scene_invalidate) rt_scene_invalidate(scene);
-  isize depth      = bvh_required_depth(src.len);
-  isize n_internal = bvh_n_internal_nodes(depth);
-  scene->bvh.depth           = depth;
-  scene->bvh.last_row_offset = n_internal;
-  scene->bvh.nodes.len       = n_internal;
-  scene->bvh.nodes.data      = (BVH_Node *)rt_alloc_zeroed(allocator, n_internal * (isize)sizeof(BVH_Node), 64);
-  memset(&scene->triangles, 0, sizeof scene->triangles);
-  if (!scene->bvh.nodes.data) { scene->bvh.nodes.len = 0; return; }
-  if (!triangles_init(&scene->triangles, bvh_n_leaf_nodes(depth) * RT_BVH_WIDTH, allocator)) {
-    memset(&scene->triangles, 0, sizeof scene->triangles);
-    return;
-  }
+  if (!rt_scene_alloc(scene, src.len, allocator)) return;
+  isize depth = scene->bvh.depth;
   if (src.len <= 0) return;
 
   isize n = src.len;

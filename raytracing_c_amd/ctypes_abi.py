@@ -143,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "render_thread_proc", "rendering_context_is_finished", "rendering_context_finish", "lightmap_bake", "render",
     "denoise_image",
     # rt_scene.h (reference scene.h:101)
-    "scene_init", "scene_init_sah", "rt_scene_free", "scene_load_bytes", "scene_save_bytes", "scene_file_size",
+    "scene_init", "scene_init_sah", "scene_init_gpu", "rt_scene_alloc", "rt_scene_free", "scene_load_bytes", "scene_save_bytes", "scene_file_size",
     # rt_materials.h (reference driver.c:95,350,411)
     "disney_shader_proc", "debug_shader_proc", "sample_background",
     # rt_hip.h

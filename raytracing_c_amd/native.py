@@ -83,6 +83,9 @@ def _declare(d):
     d.scene_init.restype = None
     d.scene_init_sah.argtypes = [P(abi.Scene), abi.Triangle_Slice, abi.Allocator]
     d.scene_init_sah.restype = None
+    d.scene_init_gpu.argtypes = [P(abi.Scene), abi.Triangle_Slice, abi.Allocator]
+    d.rt_scene_alloc.argtypes = [P(abi.Scene), abi.isize, abi.Allocator]
+    d.rt_scene_alloc.restype = C.c_bool
     d.rt_scene_free.argtypes = [P(abi.Scene)]
     d.rt_scene_free.restype = None
     d.scene_load_bytes.argtypes = [abi.Byte_Slice, P(abi.Scene)]

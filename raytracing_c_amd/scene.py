@@ -13,7 +13,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import ctypes_abi as abi
-from .native import lib, symbol_address
+from .native import lib, last_error, symbol_address
 
 
 @dataclass
@@ -195,6 +195,9 @@ def build_scene(positions, normals, uvs, material_ids, materials: List[Material]
         lib.scene_init(C.byref(hs.scene), sl, abi.Allocator(None, None))          # scene.c:416-426
     elif builder == "sah":
         lib.scene_init_sah(C.byref(hs.scene), sl, abi.Allocator(None, None))      # opt-in quality builder, same layout
+    elif builder == "gpu":
+        if lib.scene_init_gpu(C.byref(hs.scene), sl, abi.Allocator(None, None)) != 0:   # scene_init by GPU kernels, same bytes
+            raise RuntimeError("scene_init_gpu: " + last_error())
     else:
         raise ValueError(f"unknown BVH builder {builder!r}")
     hs.builder = builder

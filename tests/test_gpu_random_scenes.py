@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def make_scene(seed, n_tris, depth_hint=None):
+def make_scene(seed, n_tris, depth_hint=None, builder="reference"):
     from raytracing_c_amd.background import procedural_background
     from raytracing_c_amd.loaders import camera_from_trs
     from raytracing_c_amd.scene import Material, build_scene
@@ -48,7 +48,7 @@ def make_scene(seed, n_tris, depth_hint=None):
     ids = rng.integers(0, len(mats), n_tris)
     cam = camera_from_trs((0.1, 0.2, 3.5))
     bg = procedural_background(64, 32)
-    return build_scene(P, N, UV, ids, mats, images, cam, 0.9, bg)
+    return build_scene(P, N, UV, ids, mats, images, cam, 0.9, bg, builder=builder)
 
 
 @pytest.mark.parametrize("seed,n_tris", [(1, 5), (2, 8), (3, 9), (4, 64), (5, 65), (6, 400), (7, 513), (8, 3000),
