@@ -2,13 +2,12 @@
  * raytracer.c (driver.c:747-837): build a Scene with scene_init, fill a Rendering_Context, start T threads on
  * render_thread_proc, poll rendering_context_is_finished, optionally denoise, write the image.
  *
- *   cc -std=gnu11 -O2 -Iinclude examples/driver_min.c -Lraytracing_c_amd -lrt_hip -lpthread \
- *      -Wl,-rpath,$PWD/raytracing_c_amd -o examples/driver_min
- *   examples/driver_min scene.rtscene W H SAMPLES BOUNCES THREADS out.ppm [-D]
+ *   make -C examples        (cc -std=gnu11 ... driver_min.c rt_model.c -lrt_hip -lpthread -lm)
+ *   examples/driver_min MODEL W H SAMPLES BOUNCES THREADS out.ppm [-D] [--background bg.rgb8] [--camera "tx ty tz qx qy qz qw fov"]
  *
- * The input is a flat dump of what driver.c's loaders produce (triangles, PBR_Shader_Data, images, camera);
- * raytracing_c_amd/scene_dump.py writes it.  This file is the reference-side binding of INTEGRATION.md in
- * compilable form.
+ * MODEL is a model file as in driver.c:685-728 -- `.obj`, `.glb`, `.gltf`, loaded by rt_model.c (textures and the
+ * environment map from RT8I side files, tools/extract_textures.py) -- or a `.rtscene` dump of what the loaders produce
+ * (raytracing_c_amd/scene_dump.py).  This file is the reference-side binding of INTEGRATION.md in compilable form.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -17,6 +16,7 @@
 #include <unistd.h>
 
 #include "rt_hip.h"
+#include "rt_model.h"
 
 typedef struct { i32 magic, version, n_triangles, n_materials, n_images, background; } Dump_Header;
 typedef struct { f32 pos[9], nrm[9], uv[6]; i32 material; } Dump_Triangle;
@@ -34,12 +34,55 @@ static int die(char const *msg) {
   return 1;
 }
 
+static int render_and_write(Scene *scene, int width, int height, int samples, int bounces, int n_threads, int denoise, char const *out_path);
+
+/* driver.c:685-728 + :758-775: model file -> triangles, materials, images, camera; environment map; scene_init */
+static int main_model(int argc, char **argv, int width, int height, int samples, int bounces, int n_threads) {
+  int denoise = 0;
+  char const *bg_path = NULL, *cam_text = NULL;
+  for (int i = 8; i < argc; i++) {
+    if (!strcmp(argv[i], "-D")) denoise = 1;
+    else if (!strcmp(argv[i], "--background") && i + 1 < argc) bg_path = argv[++i];
+    else if (!strcmp(argv[i], "--camera") && i + 1 < argc) cam_text = argv[++i];
+  }
+  char err[512] = "";
+  RT_Model model;
+  if (!rt_model_load(argv[1], &model, err, sizeof err)) { fprintf(stderr, "driver_min: %s\n", err); return 1; }
+  static Image background;
+  static byte grey[6] = {128, 128, 128, 128, 128, 128};
+  if (bg_path) {
+    if (!rt_model_load_rgb8(bg_path, &background, err, sizeof err)) { fprintf(stderr, "driver_min: %s\n", err); return 1; }
+  } else {                                             /* background.png is a missing blob of the reference */
+    background = (Image){ .components = 3, .pixel_type = PT_u8, .width = 2, .stride = 2, .height = 1, .pixels = { grey, 6 } };
+  }
+  Scene scene;
+  memset(&scene, 0, sizeof scene);
+  scene.background = (Background){ .proc = (Background_Proc)sample_background, .data = &background };            /* driver.c:760-763 */
+  scene.camera = model.has_camera ? model.camera : rt_model_default_camera();                                     /* driver.c:765-767 */
+  if (cam_text) {
+    f32 v[8];
+    if (sscanf(cam_text, "%f %f %f %f %f %f %f %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) != 8)
+      return die("--camera wants \"tx ty tz qx qy qz qw fov\"");
+    scene.camera = rt_model_camera(v, v + 3, v[7]);
+  }
+  scene_init(&scene, (Triangle_Slice){ model.triangles, model.n_triangles }, (Allocator){ 0 });                  /* driver.c:775 */
+  printf("driver_min: %s: %ld triangles, %ld materials, %ld images, BVH depth %ld\n", argv[1], (long)model.n_triangles,
+         (long)model.n_materials, (long)model.n_images, (long)scene.bvh.depth);
+  return render_and_write(&scene, width, height, samples, bounces, n_threads, denoise, argv[7]);
+}
+
+static int has_suffix(char const *s, char const *suf) {
+  size_t n = strlen(s), m = strlen(suf);
+  return n >= m && strcmp(s + n - m, suf) == 0;
+}
+
 int main(int argc, char **argv) {
-  if (argc < 8) return die("usage: driver_min scene.rtscene W H SAMPLES BOUNCES THREADS out.ppm [-D]");
+  if (argc < 8) return die("usage: driver_min MODEL W H SAMPLES BOUNCES THREADS out.ppm [-D] [--background bg.rgb8] [--camera \"tx ty tz qx qy qz qw fov\"]");
   int width = atoi(argv[2]), height = atoi(argv[3]), samples = atoi(argv[4]), bounces = atoi(argv[5]);
   int n_threads = atoi(argv[6]);
   int denoise = argc > 8 && strcmp(argv[8], "-D") == 0;
   if (n_threads < 1 || n_threads > 64) return die("THREADS must be 1..64");
+  if (!has_suffix(argv[1], ".rtscene")) return main_model(argc, argv, width, height, samples, bounces, n_threads);
 
   FILE *f = fopen(argv[1], "rb");
   if (!f) return die("cannot open scene file");
@@ -93,7 +136,11 @@ int main(int argc, char **argv) {
   scene.background = (Background){ .proc = (Background_Proc)sample_background, .data = &images[hd.background] };   /* driver.c:760-763 */
   scene.camera = camera;
   scene_init(&scene, (Triangle_Slice){ tris, hd.n_triangles }, (Allocator){ 0 });                                  /* driver.c:775 */
+  return render_and_write(&scene, width, height, samples, bounces, n_threads, denoise, argv[7]);
+}
 
+static int render_and_write(Scene *scene_p, int width, int height, int samples, int bounces, int n_threads, int denoise, char const *out_path) {
+  Scene scene = *scene_p;
   Image image = { .components = 3, .pixel_type = PT_u8, .width = width, .stride = width, .height = height };       /* driver.c:747-754 */
   image.pixels.len = (isize)width * height * 3;
   image.pixels.data = aligned_alloc(64, ((size_t)image.pixels.len + 63) / 64 * 64);
@@ -116,12 +163,12 @@ int main(int argc, char **argv) {
     image = denoised;
   }
 
-  FILE *o = fopen(argv[7], "wb");
+  FILE *o = fopen(out_path, "wb");
   if (!o) return die("cannot open output");
   fprintf(o, "P6\n%d %d\n255\n", width, height);
   fwrite(image.pixels.data, 1, (size_t)image.pixels.len, o);
   fclose(o);
   printf("driver_min: %dx%d, %d spp, %d bounces, %d thread(s), chunk counter %d -> %s\n", width, height, samples, bounces,
-         n_threads, (int)ctx._current_chunk, argv[7]);
+         n_threads, (int)ctx._current_chunk, out_path);
   return 0;
 }

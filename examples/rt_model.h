@@ -1,0 +1,46 @@
+/* rt_model.h -- C model loading for a host of librt_hip.so: what driver.c:510-728 does with codin's obj.h / gltf.h /
+ * stb_image (none of which are in the reference tree).  `.obj` (+ `.mtl`) and `.glb` / `.gltf` files become the
+ * Triangle[] + PBR_Shader_Data[] + Image[] (+ Camera) that scene_init() and render_thread_proc() consume.
+ *
+ * No image decoder is linked: the texels of image k of a model come from the side file `<model path>.image<k>.rgb8`
+ * (16-byte header "RT8I", i32 width, height, components, then the rows; tools/extract_textures.py writes them from
+ * the JPEG / PNG data with PIL).  A material that references an image whose side file is missing fails the load.
+ *
+ * Semantics follow raytracing_c_amd/loaders.py (the loader the benchmark configs use) field for field: material
+ * defaults of driver.c:549-568 (OBJ) and :628-639 (glTF, with the glTF-spec defaults metallic = roughness = 1 where
+ * the file omits a factor), node TRS / matrix transforms applied to positions and normals, first perspective camera
+ * node (driver.c:599-612), fan triangulation of OBJ polygons, face normals where a file has none.
+ */
+#ifndef RT_MODEL_H
+#define RT_MODEL_H
+
+#include <stddef.h>
+
+#include "rt_raytracer.h"
+#include "rt_materials.h"
+
+typedef struct {
+  Triangle        *triangles;      /* shader = { &materials[k], disney_shader_proc } (driver.c:574-577, 670-673) */
+  isize            n_triangles;
+  PBR_Shader_Data *materials;
+  isize            n_materials;
+  Image           *images;         /* RGB8, stride == width */
+  isize            n_images;
+  bool             has_camera;     /* glTF: first perspective camera node; OBJ: never */
+  Camera           camera;         /* view_matrix (node transform), fov = yfov, focal_length = 1 / tan(fov / 2) */
+} RT_Model;
+
+/* Dispatch on the file suffix as driver.c:685-728.  false + message in err on any failure. */
+bool rt_model_load(char const *path, RT_Model *out, char *err, size_t err_len);
+void rt_model_free(RT_Model *model);
+
+/* driver.c:765-767: T = (0, 0, 3), R = I, fov = 70 degrees */
+Camera rt_model_default_camera(void);
+
+/* matrix_4x4_translation_rotation_scale of driver.c:765 (quaternion x, y, z, w; unit scale) + field of view in radians */
+Camera rt_model_camera(f32 const translation[3], f32 const rotation[4], f32 yfov);
+
+/* one RT8I side file (what image k of a model is read from) -> Image; used for the environment map too */
+bool rt_model_load_rgb8(char const *path, Image *out, char *err, size_t err_len);
+
+#endif /* RT_MODEL_H */

@@ -1,0 +1,164 @@
+"""examples/rt_model.c: model loading in C for a host of librt_hip.so (driver.c:510-728 does it with
+codin's obj.h / gltf.h / stb_image, which are not in the reference tree).  Textures come from RT8I side files
+(tools/extract_textures.py), so no image decoder is linked.
+
+The C loader is checked against the Python loader the benchmark configs use (same triangles, normals, uvs, materials,
+texture assignment, camera), and -- on the GPU -- through examples/driver_min: a C host that takes a MODEL PATH like
+driver.c:685-728 renders the same bytes as the oracle on the C-loaded scene."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "examples")
+ASSETS = os.path.join(ROOT, "assets")
+
+
+def _lib():
+    from raytracing_c_amd import ctypes_abi as abi
+    import raytracing_c_amd as rt
+    rt.lib.rt_last_error()                                   # librt_hip.so first (librt_model.so links against it)
+    subprocess.check_call(["make", "-C", EX], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(EX, "librt_model.so"))
+
+    class RT_Model(C.Structure):
+        _fields_ = [("triangles", C.c_void_p), ("n_triangles", abi.isize), ("materials", C.POINTER(abi.PBR_Shader_Data)),
+                    ("n_materials", abi.isize), ("images", C.POINTER(abi.Image)), ("n_images", abi.isize),
+                    ("has_camera", C.c_bool), ("camera", abi.Camera)]
+
+    lib.rt_model_load.argtypes = [C.c_char_p, C.POINTER(RT_Model), C.c_char_p, C.c_size_t]
+    lib.rt_model_load.restype = C.c_bool
+    lib.rt_model_free.argtypes = [C.POINTER(RT_Model)]
+    lib.rt_model_default_camera.restype = abi.Camera
+    lib.rt_model_camera.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float]
+    lib.rt_model_camera.restype = abi.Camera
+    return lib, RT_Model
+
+
+def _load_c(prefix):
+    """C loader output as the numpy arrays / Material list raytracing_c_amd.scene.build_scene takes."""
+    from raytracing_c_amd import ctypes_abi as abi
+    from raytracing_c_amd.scene import Material
+    lib, RT_Model = _lib()
+    m = RT_Model()
+    err = C.create_string_buffer(512)
+    assert lib.rt_model_load(prefix.encode(), C.byref(m), err, 512), err.value.decode()
+    n = int(m.n_triangles)
+    tri = np.frombuffer(C.string_at(m.triangles, n * abi.TRIANGLE_DTYPE.itemsize), abi.TRIANGLE_DTYPE).copy()
+    mat_base = C.addressof(m.materials.contents)
+    img_base = C.addressof(m.images.contents) if m.n_images else 0
+
+    def tex(ptr):
+        return None if not ptr else (C.addressof(ptr.contents) - img_base) // C.sizeof(abi.Image)
+
+    mats = []
+    for k in range(int(m.n_materials)):
+        d = m.materials[k]
+        mats.append(Material(base_color=(d.base_color.x, d.base_color.y, d.base_color.z),
+                             emission=(d.emission.x, d.emission.y, d.emission.z), roughness=d.roughness, metalness=d.metalness,
+                             normal_map_strength=d.normal_map_strength, sheen=d.sheen, sheen_tint=d.sheen_tint,
+                             anisotropic_strength=d.anisotropic_strength, texture_albedo=tex(d.texture_albedo),
+                             texture_normal=tex(d.texture_normal), texture_metal_roughness=tex(d.texture_metal_roughness),
+                             texture_emission=tex(d.texture_emission)))
+    images = []
+    for k in range(int(m.n_images)):
+        im = m.images[k]
+        if im.pixels.data:
+            images.append(np.frombuffer(C.string_at(im.pixels.data, im.pixels.len), np.uint8).reshape(im.height, im.width, im.components).copy())
+        else:
+            images.append(np.zeros((1, 1, 3), np.uint8))            # an image no material uses: not loaded
+    out = dict(positions=tri["positions"].copy(), normals=tri["normals"].copy(), uvs=tri["tex_coords"].copy(),
+               material_ids=((tri["shader_data"].astype(np.int64) - mat_base) // C.sizeof(abi.PBR_Shader_Data)),
+               materials=mats, images=images, camera=None)
+    if m.has_camera:
+        cam = np.ctypeslib.as_array(m.camera.view_matrix.rows).reshape(4, 4).copy()
+        out["camera"] = (cam, float(m.camera.fov), float(m.camera.focal_length))
+    lib.rt_model_free(C.byref(m))
+    return out
+
+
+@pytest.mark.parametrize("asset", ["quad.obj", "tower.obj", "fov_test.obj", "spheres.glb", "sheen.glb", "helmet.glb"])
+def test_c_loader_matches_the_python_loader(tmp_path, asset):
+    from raytracing_c_amd.loaders import load_model_data
+    from tools.extract_textures import extract
+    prefix = extract(os.path.join(ASSETS, asset), str(tmp_path))
+    c = _load_c(prefix)
+    p = load_model_data(os.path.join(ASSETS, asset))
+    assert c["positions"].shape == p["positions"].shape
+    assert np.array_equal(c["material_ids"], p["material_ids"])
+    assert np.array_equal(c["uvs"], p["uvs"])
+    exact = asset.endswith(".obj")                            # text -> strtod -> f32 on both sides: identical
+    for key in ("positions", "normals"):
+        a, b = c[key], p[key].astype(np.float32)
+        if exact:
+            assert np.array_equal(a, b), key
+        else:                                                 # node transforms: float64 sums in a different order (BLAS vs loops)
+            assert np.allclose(a, b, rtol=0, atol=2e-7), key
+            assert (a == b).mean() > 0.999, (key, (a == b).mean())
+    assert len(c["materials"]) == len(p["materials"])
+    for mc, mp in zip(c["materials"], p["materials"]):
+        for f in ("roughness", "metalness", "normal_map_strength", "sheen", "sheen_tint", "anisotropic_strength"):
+            assert np.float32(getattr(mc, f)) == np.float32(getattr(mp, f)), f
+        assert np.array_equal(np.float32(mc.base_color), np.float32(mp.base_color))
+        assert np.array_equal(np.float32(mc.emission), np.float32(mp.emission))
+        for f in ("texture_albedo", "texture_normal", "texture_metal_roughness", "texture_emission"):
+            assert getattr(mc, f) == getattr(mp, f), f
+    for k, im in enumerate(p["images"]):
+        if any(k in (m.texture_albedo, m.texture_normal, m.texture_metal_roughness, m.texture_emission) for m in p["materials"]):
+            assert np.array_equal(c["images"][k], im)
+    if p["camera"] is None:
+        assert c["camera"] is None
+    else:
+        assert np.array_equal(c["camera"][0], p["camera"][0].astype(np.float32))
+        assert np.float32(c["camera"][1]) == np.float32(p["camera"][1])
+        focal = np.float32(1.0) / np.tan(np.float32(p["camera"][1]) * np.float32(0.5), dtype=np.float32)
+        assert abs(np.float32(c["camera"][2]) - focal) <= 2 * np.spacing(focal)      # tanf vs numpy's float32 tan: <= 1 ulp apart
+
+
+def test_c_loader_fails_loudly(tmp_path):
+    lib, RT_Model = _lib()
+    m = RT_Model()
+    err = C.create_string_buffer(512)
+    assert not lib.rt_model_load(str(tmp_path / "nothing.obj").encode(), C.byref(m), err, 512) and b"cannot read" in err.value
+    assert not lib.rt_model_load(b"model.fbx", C.byref(m), err, 512) and b"Unrecognized file type" in err.value     # driver.c:724-727
+    link = tmp_path / "helmet.glb"                            # textures referenced, side files missing
+    os.symlink(os.path.join(ASSETS, "helmet.glb"), link)
+    assert not lib.rt_model_load(str(link).encode(), C.byref(m), err, 512) and b"side file" in err.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("asset,camera", [("helmet.glb", None), ("spheres.glb", None), ("tower.obj", "0 12.5 32 0 0 0 1 1.2217305")])
+def test_c_driver_takes_a_model_path(tmp_path, oracle, asset, camera):
+    """driver_min MODEL ... : load with rt_model.c, scene_init, render_thread_proc threads, PPM -- byte-equal to the oracle's
+    render of the same C-loaded scene (camera of the file, or the override the tower config needs)."""
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.scene import build_scene
+    from tests import _oracle
+    from tests.test_c_driver import _read_ppm
+    from tools.extract_textures import extract
+    prefix = extract(os.path.join(ASSETS, asset), str(tmp_path), background=True)
+    out = str(tmp_path / "o.ppm")
+    w, h, s, b = 96, 54, 4, 6
+    cmd = [os.path.join(EX, "driver_min"), prefix, str(w), str(h), str(s), str(b), "3", out, "--background", prefix + ".background.rgb8"]
+    if camera:
+        cmd += ["--camera", camera]
+    _lib()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = _read_ppm(out)
+    c = _load_c(prefix)
+    if camera:                                                # the same override, built by the same C function the driver calls
+        lib, _ = _lib()
+        v = (C.c_float * 8)(*[float(x) for x in camera.split()])
+        cc = lib.rt_model_camera(C.cast(v, C.POINTER(C.c_float)), C.cast(C.byref(v, 12), C.POINTER(C.c_float)), v[7])
+        cam, fov, focal = np.ctypeslib.as_array(cc.view_matrix.rows).reshape(4, 4).copy(), float(cc.fov), float(cc.focal_length)
+    else:
+        cam, fov, focal = c["camera"]
+    hs = build_scene(c["positions"], c["normals"], c["uvs"], c["material_ids"], c["materials"], c["images"], cam, fov,
+                     procedural_background())
+    hs.scene.camera.focal_length = focal                      # the C loader's tanf, not numpy's float32 tan
+    want = _oracle.render(hs, w, h, s, b)["image"]
+    assert np.array_equal(got, want)
