@@ -1143,17 +1143,18 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // what changes is where the work comes from and how the loop is cut:
 //
 //  * A wave OWNS an 8x8-pixel tile (taken from the head counter, expensive tiles first) and pulls UNITS of it --
-//    2 pixels x 2^chunk_shift samples, four (one tile row) per atomic while the tile has plenty left -- from the tile's
-//    own counter `tile_next[tile]` until the tile is exhausted.  Lanes whose path ended are refilled across chunk boundaries, so there is no end-of-item drain
-//    between chunks (the scheduled kernel drains the wave at the end of every item, ~40 us each); the wave drains
-//    once per TILE.  Chunks are pixel-major, so the 64 lanes still sit on two or three pixels (coherent nodes,
-//    leaves and texels) whatever the chunk size.
-//  * When the head counter runs dry a wave JOINS a tile that still has chunks (two-level scan with agent-scope
-//    loads: `open_groups[g]` counts the open tiles of every group of 64) and pulls from the same counter: the tail of a launch is balanced at chunk
-//    granularity (256 paths) even when a rank of the 8-GPU partition has fewer tiles than the chip has waves.
-//    Every chunk is handed out exactly once by an atomic; radiance sums are order-free integers, so results do
-//    not depend on who traced what.  Owners always finish their tile, so a joiner may give up at any time:
-//    every wave reaches an exit (bounded scans), there is no inter-wave dependency and no grid barrier.
+//    2 neighbouring pixels x 2^chunk_shift samples (64 paths at 32 samples: one wave-load, pixel-major, so the 64 lanes
+//    sit on two pixels: coherent nodes, leaves and texels), one or two per atomic -- from the tile's own counter
+//    `tile_next[tile]` until the tile is exhausted.  Lanes whose path ended are refilled across unit boundaries, so
+//    there is no end-of-item drain (the scheduled kernel drains the wave at the end of every item, 40 us to 0.4 ms each);
+//    the wave drains once per TILE.
+//  * When the head counter runs dry a wave JOINS a tile that still has units (two-level scan with agent-scope loads:
+//    `open_groups[g]` counts the open tiles of every group of 64) and pulls from the same counter: the tail of a
+//    launch is balanced at unit granularity even when a rank of the 8-GPU partition has fewer tiles than the chip has
+//    waves.  Every unit is handed out exactly once by an atomic; radiance sums are order-free integers, so results do
+//    not depend on who traced what.  Owners always finish their tile, so a joiner may give up at any time: every wave
+//    reaches an exit (bounded scans), there is no inter-wave dependency and no grid barrier.
+//  * Camera rays of a tile whose pixel pyramid misses every child box of the root skip the root block (below).
 //  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
@@ -1215,7 +1216,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   uint32_t n_tiles_done = 0;
   unsigned long long t_last_grab = 0ull;
 
-  const int shift = P.chunk_shift;                 // samples per chunk = 1 << shift
+  const int shift = P.chunk_shift;                 // samples per unit = 1 << shift
   const int unit_paths = 2 << shift;               // a unit = 2 neighbouring pixels x (1 << shift) samples
   const uint32_t n_chunks_tile = (uint32_t)P.n_chunks_tile;      // units per tile: 8 rows x sample blocks x 4 pixel pairs
   const int leaf_level = P.depth - 1;
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   int  steal_tries = 0;
 
   for (;;) {
-    // ---------------- take a tile: own one from the queue, or join one that still has chunks ----------------
+    // ---------------- take a tile: own one from the queue, or join one that still has units ----------------
     int tile_idx = -1;
     if (queue_open) {
       RT_KArgs A = cold_args();
@@ -1356,9 +1357,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
 
     // The tile hands out UNITS (2 pixels x one block of samples = 64 paths at 32 samples: one wave-load, lanes on two
-    // pixels).  A wave grabs 4 consecutive units (one row of the tile for one sample block) per atomic while the tile
-    // has plenty left, 2 and then 1 towards its end: the last units of a launch are spread over the waves that
-    // join the tile instead of keeping one wave busy for 256 paths.  Current unit (wave-uniform): paths
+    // pixels).  A wave grabs `grab_max` consecutive units per atomic while the tile has plenty left, fewer towards its
+    // end: what a wave still holds when the launch runs dry is its tail.  Current unit (wave-uniform): paths
     // [c_next, c_end) at pixels (c_x0 .. c_x0 + 1, c_y), samples from c_s0.
     bool tile_open = true;
     int  c_next = 0, c_end = 0, c_x0 = 0, c_y = 0, c_pix0 = 0, c_s0 = 0;
