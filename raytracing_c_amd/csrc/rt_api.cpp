@@ -881,6 +881,10 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     // per wave (a rank of the 8-GPU partition: 4 -> 6.97 / 7.14 / 6.79 ms, 2 -> 6.72 / 6.77 / 6.46, 1 -> 6.65 / 6.66 / 6.45):
     // what a wave still holds when the launch runs dry is its tail
     K.grab_max = (int64_t)K.n_tiles < (int64_t)2 * n_waves ? 1 : 2;
+    K.pyr_nodes = K.n_lds_nodes;
+    if (const char *e = getenv("RT_PYRAMID")) {
+      if (atoi(e) == 0) K.pyr_nodes = 0;
+    }
     if (const char *e = getenv("RT_GRAB")) {
       int v = atoi(e);
       if (v == 1 || v == 2 || v == 4) K.grab_max = v;

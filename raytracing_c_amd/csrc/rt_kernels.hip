@@ -1158,6 +1158,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 //  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
+#ifndef RT_PYR_NUM
+#define RT_PYR_NUM 3       // a pyramid-culled node block needs nG >= nN * RT_PYR_NUM / RT_PYR_DEN camera rays on one node
+#define RT_PYR_DEN 4
+#define RT_PYR_MIN 8
+#endif
 #define RT_STEAL_TRIES  16        // failed joins in a row before a wave retires
 
 // Kernel arguments that are only needed outside the traversal loop (camera, frame and tile bookkeeping, material
@@ -1165,6 +1170,83 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // kept live across the traversal loop they cost ~50 scalar registers, and the spills of those (to VGPR lanes, then
 // VGPRs to scratch) were measured at +3 % frame time.  A scalar load per use in the shade / regenerate block is free
 // by comparison (that block runs once per ~4.6 traversal blocks and is several hundred instructions long).
+// ---- pyramid culling of node blocks (tile-stream kernel) ----
+// `pyr` (LDS, per wave): outward normals of the four side planes of the tile's camera-ray pyramid at [4 q .. 4 q + 2],
+// the common ray origin at [16 .. 18].  Lane l tests child (l & 7) of LDS node `node` against plane ((l >> 3) & 3);
+// returns the 8-bit mask of the children that NO ray inside the pyramid can enter (outside one plane by a relative
+// margin of 1e-3, or the all-zero box of an unpopulated child): ray_aabbs_hit_8 reports a miss for each of them
+// (raytracer.c:190-230), whatever the ray's t_max.
+__device__ __forceinline__ uint32_t pyramid_cull_mask(const float4 *lds_nodes, const float *pyr, int node) {
+  int lane = (int)threadIdx.x;
+  asm volatile("" : "+v"(lane));       // opaque: the lane's addresses are formed here, not kept in registers across the loops
+  const float *nb = reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4) + (lane & 7);
+  const float *pl = pyr + ((lane >> 3) & 3) * 4;
+  const float ox = pyr[16], oy = pyr[17], oz = pyr[18];
+  const float mnx = nb[0], mny = nb[8], mnz = nb[16], mxx = nb[24], mxy = nb[32], mxz = nb[40];
+  const float nx = pl[0], ny = pl[1], nz = pl[2];
+  const bool empty = mnx == 0.0f && mny == 0.0f && mnz == 0.0f && mxx == 0.0f && mxy == 0.0f && mxz == 0.0f;
+  const float lox = nx * (mnx - ox), hix = nx * (mxx - ox), loy = ny * (mny - oy), hiy = ny * (mxy - oy);
+  const float loz = nz * (mnz - oz), hiz = nz * (mxz - oz);
+  const float nearest = fminf(lox, hix) + fminf(loy, hiy) + fminf(loz, hiz);       // smallest n . (p - o) over the box
+  const float extent = fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz));
+  const bool outside = empty || nearest > 1e-3f * extent;                           // (NaN compares false: not outside)
+  const uint32_t m = (uint32_t)__ballot(outside);                                  // lanes 0..31: 4 planes x 8 children
+  return (m | (m >> 8) | (m >> 16) | (m >> 24)) & 0xFFu;
+}
+
+// node_enter() for a node of which only the children in `surv` (1 to 4 of them, wave-uniform) can be entered: the
+// same word -- the other children are misses, which rank behind every candidate and are never read.
+__device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *lds_nodes, int node, uint32_t surv,
+                                                   float hit_t) {
+  const float *nf = reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4);
+  const int n = (int)__popc(surv);
+  const int k0 = (int)__builtin_ctz(surv);
+  const float *b0 = nf + k0;
+  const int e0 = as_i(slab_entry<true>(r, b0[0], b0[8], b0[16], b0[24], b0[32], b0[40], hit_t));
+  const uint32_t f0 = 1u - (((uint32_t)e0 + 0x00800000u) >> 31);                   // 1 iff e0 is finite (a candidate)
+  if (n == 1) return (uint32_t)k0 | (f0 << 24);
+  surv &= surv - 1u;
+  const int k1 = (int)__builtin_ctz(surv);
+  const float *b1 = nf + k1;
+  const int e1 = as_i(slab_entry<true>(r, b1[0], b1[8], b1[16], b1[24], b1[32], b1[40], hit_t));
+  const uint32_t f1 = 1u - (((uint32_t)e1 + 0x00800000u) >> 31);
+  if (n == 2) {
+    const bool swap = e1 < e0;                                                     // ties: lowest index first
+    const uint32_t first = swap ? (uint32_t)k1 : (uint32_t)k0, second = swap ? (uint32_t)k0 : (uint32_t)k1;
+    return first | (second << 3) | ((f0 + f1) << 24);
+  }
+  surv &= surv - 1u;
+  const int k2 = (int)__builtin_ctz(surv);
+  const float *b2 = nf + k2;
+  const int e2 = as_i(slab_entry<true>(r, b2[0], b2[8], b2[16], b2[24], b2[32], b2[40], hit_t));
+  const uint32_t f2 = 1u - (((uint32_t)e2 + 0x00800000u) >> 31);
+  int e3 = 0x7F800000, k3 = 0;
+  uint32_t f3 = 0;
+  if (n == 4) {
+    surv &= surv - 1u;
+    k3 = (int)__builtin_ctz(surv);
+    const float *b3 = nf + k3;
+    e3 = as_i(slab_entry<true>(r, b3[0], b3[8], b3[16], b3[24], b3[32], b3[40], hit_t));
+    f3 = 1u - (((uint32_t)e3 + 0x00800000u) >> 31);
+  }
+  const int e[4] = {e0, e1, e2, e3};
+  const int kk[4] = {k0, k1, k2, k3};
+  int rank[4] = {0, 1, 2, 3};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+#pragma unroll
+    for (int k = j + 1; k < 4; k++) {
+      int kb = (int)((uint32_t)(e[k] - e[j]) >> 31);      // 1 iff e[k] < e[j]
+      rank[j] += kb;
+      rank[k] -= kb;
+    }
+  }
+  uint32_t w = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) w |= (uint32_t)kk[j] << (3 * rank[j]);
+  return w | ((f0 + f1 + f2 + f3) << 24);
+}
+
 typedef const RT_KParams __attribute__((address_space(4))) *RT_KArgs;
 __device__ __forceinline__ RT_KArgs cold_args() {
   RT_KArgs p = (RT_KArgs)__builtin_amdgcn_kernarg_segment_ptr();      // the RT_KParams block is the kernel's only argument
@@ -1196,6 +1278,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   float4 *wave_base = smem + n_lds * RT_LDS_NODE_F4 + wave * (perm_f4 + 96);
   uint32_t *perm = reinterpret_cast<uint32_t *>(wave_base);
   unsigned long long *acc = reinterpret_cast<unsigned long long *>(wave_base + perm_f4);
+  // the perm row of the deepest node level is never written (a leaf-level node has no node below it): it holds the
+  // tile's camera-ray pyramid
+  float *pyr = reinterpret_cast<float *>(wave_base + perm_f4 - 16);
 
   if (LDSN) {
     const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
@@ -1213,6 +1298,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   // wave-level counters (scalar registers)
   uint32_t w_paths = 0, w_rays = 0, w_nodes = 0, w_leaves = 0, w_shades = 0, w_bgs = 0, w_tex = 0;
   const unsigned long long t_wave_start = cold_args()->wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // RT_WAVE_TIMES only
+#ifdef RT_EXP_NODESTATS
+  uint32_t xs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   uint32_t n_tiles_done = 0;
   unsigned long long t_last_grab = 0ull;
 
@@ -1222,6 +1310,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   const int leaf_level = P.depth - 1;
   const int thresh = P.sched_thresh;
   const int drain_thresh = P.drain_thresh;
+  const int pyr_nodes = LDSN ? P.pyr_nodes : 0;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int wave_id = (int)blockIdx.x * WAVES + wave;
 
@@ -1322,6 +1411,18 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                           A->cam[2][0] * cx + A->cam[2][1] * cy + A->cam[2][2] * cz);
       }
       const rt_v3 o = rt_v3_make(A->cam[0][3], A->cam[1][3], A->cam[2][3]);
+      rt_v3 pn[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        rt_v3 n = rt_v3_cross(c[q], c[(q + 1) & 3]);
+        if (rt_v3_dot(n, c[(q + 2) & 3]) > 0.0f) n = rt_v3_scale(n, -1.0f);      // outward: the opposite corner is inside
+        pn[q] = n;
+      }
+      if (lane == 0) {                                         // the pyramid of this tile, for the node blocks
+#pragma unroll
+        for (int q = 0; q < 4; q++) { pyr[q * 4 + 0] = pn[q].x; pyr[q * 4 + 1] = pn[q].y; pyr[q * 4 + 2] = pn[q].z; }
+        pyr[16] = o.x; pyr[17] = o.y; pyr[18] = o.z;
+      }
       bool may_hit = false;
       if (lane < 8) {
         const float *nb = P.nodes + lane;                      // child `lane` of node 0: rows are 8 floats apart
@@ -1331,8 +1432,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         bool outside = empty;                                  // the all-zero box of an unpopulated child never hits
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          rt_v3 n = rt_v3_cross(c[q], c[(q + 1) & 3]);
-          if (rt_v3_dot(n, c[(q + 2) & 3]) > 0.0f) n = rt_v3_scale(n, -1.0f);      // outward: the opposite corner is inside
+          rt_v3 n = pn[q];
           float lox = n.x * lo.x, hix = n.x * hi.x, loy = n.y * lo.y, hiy = n.y * hi.y, loz = n.z * lo.z, hiz = n.z * hi.z;
           float nearest = fminf(lox, hix) + fminf(loy, hiy) + fminf(loz, hiz);     // smallest n . (p - o) over the box
           float extent = fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz));
@@ -1503,7 +1603,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 
       // ================= traversal: NODE / LEAF blocks until `thresh` lanes wait for S =================
       for (;;) {
-        const int nN = (int)__popcll(__ballot(phase == PH_NODE));
+        const unsigned long long maskN = __ballot(phase == PH_NODE);
+        const int nN = (int)__popcll(maskN);
         const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
         // while the tile still hands out paths, wait until `thresh` lanes want the S block (dense shading); once it is
         // exhausted nothing refills the lanes, and what matters is the latency of the remaining paths' bounce chains:
@@ -1522,15 +1623,51 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         } else {
           // ----- NODE -----
           w_nodes += (uint32_t)nN;
-          const bool all_fast = __ballot(phase == PH_NODE && !ray.fast) == 0;
-          if (phase == PH_NODE) {
+          const bool all_fast = (maskN & __ballot(!ray.fast)) == 0ull;
+#ifdef RT_EXP_NODESTATS
+          {
+            unsigned long long act = __ballot(phase == PH_NODE), cam = __ballot(phase == PH_NODE && bounce == 0);
+            xs[0] += 1; xs[1] += (uint32_t)nN; xs[2] += (uint32_t)__popcll(cam);
+            if (cam) {
+              int first = (int)__builtin_ctzll(cam);
+              int c0 = __builtin_amdgcn_readlane(child, first), p0 = __builtin_amdgcn_readlane(pix >> 1, first);
+              unsigned long long grp = __ballot(phase == PH_NODE && bounce == 0 && child == c0 && (pix >> 1) == p0);
+              unsigned long long grt = __ballot(phase == PH_NODE && bounce == 0 && child == c0);
+              xs[3] += (uint32_t)__popcll(grp); if (grp == act) xs[4] += 1;
+              if (2 * (int)__popcll(grp) >= nN) xs[5] += 1;
+              xs[7] += (uint32_t)__popcll(grt); if (grt == act) xs[8] += 1;
+            } else xs[6] += 1;
+          }
+#endif
+          // camera rays of this tile about to enter the same node: test only the children their pyramid can touch.  When
+          // they are most of the block's lanes, the block runs for them alone; the others keep waiting for a node block.
+          uint32_t surv = 0xFFFFu;
+          bool in_blk = phase == PH_NODE;
+          // (ballots of single comparisons combined with scalar ANDs: a ballot of a compound condition costs two more
+          // vector instructions)
+          const unsigned long long camN = maskN & __ballot(bounce == 0);
+          if (LDSN && all_fast && camN != 0ull) {
+            const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(camN));
+            const int nG = (int)__popcll(camN & __ballot(child == c0));
+            if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
+              surv = 0xFFu & ~pyramid_cull_mask(lds_nodes, pyr, c0);
+              if (__popc(surv) > 4) surv = 0xFFFFu;
+              else { in_blk = phase == PH_NODE && bounce == 0 && child == c0; w_nodes -= (uint32_t)(nN - nG); }
+#ifdef RT_EXP_NODESTATS
+              xs[9 + (surv == 0xFFFFu ? 5 : (int)__popc(surv))] += 1;
+#endif
+            }
+          }
+          if (in_blk) {
             if (level >= 0) {
               perm[level * 64 + lane] = cur;
               live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
             }
             node = child;
             level += 1;
-            if (all_fast) {
+            if (surv <= 0xFFu) {
+              cur = surv ? node_enter_few(ray, lds_nodes, node, surv, hit.t) : 0u;
+            } else if (all_fast) {
               if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes);
               else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
             } else {
@@ -1622,6 +1759,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     atomicAdd(counters + CNT_SHADES, (unsigned long long)w_shades);
     atomicAdd(counters + CNT_BG, (unsigned long long)w_bgs);
     atomicAdd(counters + CNT_TEXTURED, (unsigned long long)w_tex);
+#ifdef RT_EXP_NODESTATS
+    for (int i = 0; i < 16; i++) atomicAdd(counters + 8 + i, (unsigned long long)xs[i]);
+#endif
   }
 }
 

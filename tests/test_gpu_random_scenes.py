@@ -122,8 +122,9 @@ def _look_at(eye, target, up=(0.0, 1.0, 0.0)):
 @pytest.mark.parametrize("name", ["spheres", "tower", "helmet"])
 def test_tile_frustum_root_culling_never_changes_a_ray(oracle, name):
     """The tile-stream kernel lets camera rays skip the root block when the tile's pixel pyramid misses every child
-    box of the root (rt_kernels.hip, tile_misses_root) and counts them as the one node visit they would have cost.
-    That is an argument by margin, so it gets its own fuzz: cameras far away, close up, INSIDE the scene bounds, looking
+    box of the root (rt_kernels.hip, tile_root_miss) and counts them as the one node visit they would have cost; node
+    blocks whose lanes are camera rays on one node test only the child boxes that pyramid can touch (pyramid_cull_mask).
+    Both are arguments by margin, so it gets its own fuzz: cameras far away, close up, INSIDE the scene bounds, looking
     away from the scene, grazing the bounds so that tile pyramids pass within a hair of the root's boxes, narrow and wide
     fields of view, frames whose last tiles are ragged.  Radiance sums and all seven counters must equal the oracle's
     (node_visits is the sensitive one: a wrongly skipped ray would still count 1 but lose its later visits; a wrongly
@@ -153,12 +154,17 @@ def test_tile_frustum_root_culling_never_changes_a_ray(oracle, name):
     skipped_somewhere = False
     for i, (eye, target, fov) in enumerate(views):
         hs.set_camera(_look_at(eye, target), float(fov))
-        w, h, s, b = (88, 56, 2, 3) if i % 2 else (61, 43, 3, 2)
-        want = _oracle.render(hs, w, h, s, b, seed=100 + i)
-        got = rt.render_frame(hs, w, h, s, b, seed=100 + i, want_accum=True)
-        assert np.array_equal(want["accum"], got["accum"]), (name, i)
-        c = got["counters"]
-        for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
-            assert want["counters"][k] == getattr(c, k), (name, i, k)
-        skipped_somewhere |= c.backgrounds > 0
+        # few samples: a wave mixes many pixels of the tile; 32 samples: a wave sits on two pixels, whole node blocks of
+        # camera rays on one node -- the blocks that test only the children the tile's pyramid can touch
+        shapes = [(88, 56, 2, 3) if i % 2 else (61, 43, 3, 2)]
+        if i in (0, 3, 5, 8):
+            shapes.append((48, 40, 32, 2))
+        for w, h, s, b in shapes:
+            want = _oracle.render(hs, w, h, s, b, seed=100 + i)
+            got = rt.render_frame(hs, w, h, s, b, seed=100 + i, want_accum=True)
+            assert np.array_equal(want["accum"], got["accum"]), (name, i, s)
+            c = got["counters"]
+            for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+                assert want["counters"][k] == getattr(c, k), (name, i, s, k)
+            skipped_somewhere |= c.backgrounds > 0
     assert skipped_somewhere
