@@ -141,6 +141,9 @@ __device__ __forceinline__ float slab_entry_child(const float *n, const Ray3 &r)
 #define NODE_LDS    2     // per-lane reads from the workgroup's LDS copy of the top of the tree
 #define RT_LDS_NODE_F4 13 // LDS node stride in float4 (12 data + 1 pad: 13 is odd, so random nodes spread over all 16-byte slots of a bank row)
 
+// float4 index of LDS node `node`: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter
+__device__ __forceinline__ int lds_node_f4(int node) { return (int)__umul24((unsigned)node, (unsigned)RT_LDS_NODE_F4); }
+
 template <bool FAST, int MODE>
 __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t,
                                                const float4 *lds_nodes) {
@@ -152,7 +155,7 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
       d[k] = as_i(slab_entry<FAST>(r, nb[k], nb[8 + k], nb[16 + k], nb[24 + k], nb[32 + k], nb[40 + k], hit_t));
     }
   } else {
-    const float4 *nb = (MODE == NODE_LDS) ? (lds_nodes + node * RT_LDS_NODE_F4)
+    const float4 *nb = (MODE == NODE_LDS) ? (lds_nodes + lds_node_f4(node))
                                           : (reinterpret_cast<const float4 *>(P.nodes) + (size_t)node * 12);
 #pragma unroll
     for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             bool go = true;
             if ((dirty >> level) & 1u) {
               float dj;
-              if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4) + j, ray);
+              if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
               else dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
               if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
             }
@@ -1179,7 +1182,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 __device__ __forceinline__ uint32_t pyramid_cull_mask(const float4 *lds_nodes, const float *pyr, int node) {
   int lane = (int)threadIdx.x;
   asm volatile("" : "+v"(lane));       // opaque: the lane's addresses are formed here, not kept in registers across the loops
-  const float *nb = reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4) + (lane & 7);
+  const float *nb = reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + (lane & 7);
   const float *pl = pyr + ((lane >> 3) & 3) * 4;
   const float ox = pyr[16], oy = pyr[17], oz = pyr[18];
   const float mnx = nb[0], mny = nb[8], mnz = nb[16], mxx = nb[24], mxy = nb[32], mxz = nb[40];
@@ -1198,7 +1201,7 @@ __device__ __forceinline__ uint32_t pyramid_cull_mask(const float4 *lds_nodes, c
 // same word -- the other children are misses, which rank behind every candidate and are never read.
 __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *lds_nodes, int node, uint32_t surv,
                                                    float hit_t) {
-  const float *nf = reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4);
+  const float *nf = reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node));
   const int n = (int)__popc(surv);
   const int k0 = (int)__builtin_ctz(surv);
   const float *b0 = nf + k0;
@@ -1708,7 +1711,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
               bool go = true;
               if ((dirty >> level) & 1u) {
                 float dj;
-                if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + node * RT_LDS_NODE_F4) + j, ray);
+                if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
                 else dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
                 if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
               }
