@@ -1284,6 +1284,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   // the perm row of the deepest node level is never written (a leaf-level node has no node below it): it holds the
   // tile's camera-ray pyramid
   float *pyr = reinterpret_cast<float *>(wave_base + perm_f4 - 16);
+  uint32_t *pyr_cache = reinterpret_cast<uint32_t *>(pyr) + 32;      // 32 entries, direct mapped: (node + 1) << 8 | cull mask
 
   if (LDSN) {
     const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
@@ -1426,6 +1427,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         for (int q = 0; q < 4; q++) { pyr[q * 4 + 0] = pn[q].x; pyr[q * 4 + 1] = pn[q].y; pyr[q * 4 + 2] = pn[q].z; }
         pyr[16] = o.x; pyr[17] = o.y; pyr[18] = o.z;
       }
+      if (lane < 32) pyr_cache[lane] = 0u;                     // the cull masks found for this tile so far (node blocks)
       bool may_hit = false;
       if (lane < 8) {
         const float *nb = P.nodes + lane;                      // child `lane` of node 0: rows are 8 floats apart
@@ -1653,7 +1655,15 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(camN));
             const int nG = (int)__popcll(camN & __ballot(child == c0));
             if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
-              surv = 0xFFu & ~pyramid_cull_mask(lds_nodes, pyr, c0);
+              // the mask depends on (tile, node) only and the tile's camera rays keep coming back to the same nodes
+              const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)pyr_cache[c0 & 31]);
+              if ((ce >> 8) == (uint32_t)c0 + 1u) {
+                surv = 0xFFu & ~ce;
+              } else {
+                const uint32_t cull = pyramid_cull_mask(lds_nodes, pyr, c0);
+                if (lane == 0) pyr_cache[c0 & 31] = (((uint32_t)c0 + 1u) << 8) | cull;
+                surv = 0xFFu & ~cull;
+              }
               if (__popc(surv) > 4) surv = 0xFFFFu;
               else { in_blk = phase == PH_NODE && bounce == 0 && child == c0; w_nodes -= (uint32_t)(nN - nG); }
 #ifdef RT_EXP_NODESTATS
