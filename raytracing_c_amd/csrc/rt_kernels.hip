@@ -1173,6 +1173,19 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // kept live across the traversal loop they cost ~50 scalar registers, and the spills of those (to VGPR lanes, then
 // VGPRs to scratch) were measured at +3 % frame time.  A scalar load per use in the shade / regenerate block is free
 // by comparison (that block runs once per ~4.6 traversal blocks and is several hundred instructions long).
+// A wave-uniform LDS byte offset turned into a pointer WHERE it is used (the empty asm keeps the compiler from forming
+// the address once, holding it in a VGPR across the loops and spilling it to scratch), and the lane index recomputed
+// (v_mbcnt) instead of kept.
+__device__ __forceinline__ float *lds_at(float4 *smem, int byte_off) {
+  asm volatile("" : "+s"(byte_off));
+  return reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + byte_off);
+}
+__device__ __forceinline__ int lane_now() {
+  unsigned ones = ~0u;
+  asm volatile("" : "+s"(ones));
+  return (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+}
+
 // ---- pyramid culling of node blocks (tile-stream kernel) ----
 // `pyr` (LDS, per wave): outward normals of the four side planes of the tile's camera-ray pyramid at [4 q .. 4 q + 2],
 // the common ray origin at [16 .. 18].  Lane l tests child (l & 7) of LDS node `node` against plane ((l >> 3) & 3);
@@ -1180,8 +1193,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // margin of 1e-3, or the all-zero box of an unpopulated child): ray_aabbs_hit_8 reports a miss for each of them
 // (raytracer.c:190-230), whatever the ray's t_max.
 __device__ __forceinline__ uint32_t pyramid_cull_mask(const float4 *lds_nodes, const float *pyr, int node) {
-  int lane = (int)threadIdx.x;
-  asm volatile("" : "+v"(lane));       // opaque: the lane's addresses are formed here, not kept in registers across the loops
+  const int lane = lane_now();
   const float *nb = reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + (lane & 7);
   const float *pl = pyr + ((lane >> 3) & 3) * 4;
   const float ox = pyr[16], oy = pyr[17], oz = pyr[18];
@@ -1283,8 +1295,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   unsigned long long *acc = reinterpret_cast<unsigned long long *>(wave_base + perm_f4);
   // the perm row of the deepest node level is never written (a leaf-level node has no node below it): it holds the
   // tile's camera-ray pyramid
-  float *pyr = reinterpret_cast<float *>(wave_base + perm_f4 - 16);
-  uint32_t *pyr_cache = reinterpret_cast<uint32_t *>(pyr) + 32;      // 32 entries, direct mapped: (node + 1) << 8 | cull mask
+  const int acc_off = (n_lds * RT_LDS_NODE_F4 + __builtin_amdgcn_readfirstlane(wave) * (perm_f4 + 96) + perm_f4) * 16;
+  const int pyr_off = (n_lds * RT_LDS_NODE_F4 + __builtin_amdgcn_readfirstlane(wave) * (perm_f4 + 96) + perm_f4 - 16) * 16;
+  // (+ 128 bytes: 32 cache entries, direct mapped by node: (node + 1) << 8 | cull mask)
 
   if (LDSN) {
     const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
@@ -1422,12 +1435,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         if (rt_v3_dot(n, c[(q + 2) & 3]) > 0.0f) n = rt_v3_scale(n, -1.0f);      // outward: the opposite corner is inside
         pn[q] = n;
       }
+      float *pyr = lds_at(smem, pyr_off);
       if (lane == 0) {                                         // the pyramid of this tile, for the node blocks
 #pragma unroll
         for (int q = 0; q < 4; q++) { pyr[q * 4 + 0] = pn[q].x; pyr[q * 4 + 1] = pn[q].y; pyr[q * 4 + 2] = pn[q].z; }
         pyr[16] = o.x; pyr[17] = o.y; pyr[18] = o.z;
       }
-      if (lane < 32) pyr_cache[lane] = 0u;                     // the cull masks found for this tile so far (node blocks)
+      if (lane < 32) reinterpret_cast<uint32_t *>(pyr)[32 + lane] = 0u;      // the cull masks found for this tile so far
       bool may_hit = false;
       if (lane < 8) {
         const float *nb = P.nodes + lane;                      // child `lane` of node 0: rows are 8 floats apart
@@ -1492,9 +1506,12 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           done = true;
         }
         if (done) {
-          atomicAdd(&acc[pix * 3 + 0], (unsigned long long)rt_accum_quantize(radiance.x));
-          atomicAdd(&acc[pix * 3 + 1], (unsigned long long)rt_accum_quantize(radiance.y));
-          atomicAdd(&acc[pix * 3 + 2], (unsigned long long)rt_accum_quantize(radiance.z));
+          // (32-bit address arithmetic from the wave's byte offset: `acc + pix * 3` is a 64-bit multiply-add on a pointer
+          // that is kept in scratch)
+          unsigned long long *ap = reinterpret_cast<unsigned long long *>(lds_at(smem, acc_off) + pix * 6);
+          atomicAdd(ap + 0, (unsigned long long)rt_accum_quantize(radiance.x));
+          atomicAdd(ap + 1, (unsigned long long)rt_accum_quantize(radiance.y));
+          atomicAdd(ap + 2, (unsigned long long)rt_accum_quantize(radiance.z));
           phase = PH_NEED;
         }
         w_shades += (uint32_t)__popcll(__ballot(cn.shades != 0));
@@ -1656,12 +1673,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             const int nG = (int)__popcll(camN & __ballot(child == c0));
             if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
               // the mask depends on (tile, node) only and the tile's camera rays keep coming back to the same nodes
-              const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)pyr_cache[c0 & 31]);
+              float *pyr = lds_at(smem, pyr_off);
+              uint32_t *slot = reinterpret_cast<uint32_t *>(pyr) + 32 + (c0 & 31);
+              const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)*slot);
               if ((ce >> 8) == (uint32_t)c0 + 1u) {
                 surv = 0xFFu & ~ce;
               } else {
                 const uint32_t cull = pyramid_cull_mask(lds_nodes, pyr, c0);
-                if (lane == 0) pyr_cache[c0 & 31] = (((uint32_t)c0 + 1u) << 8) | cull;
+                if (lane_now() == 0) *slot = (((uint32_t)c0 + 1u) << 8) | cull;
                 surv = 0xFFu & ~cull;
               }
               if (__popc(surv) > 4) surv = 0xFFFFu;
