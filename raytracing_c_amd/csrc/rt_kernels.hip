@@ -1328,7 +1328,6 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   const int thresh = P.sched_thresh;
   const int drain_thresh = P.drain_thresh;
   const int pyr_nodes = LDSN ? P.pyr_nodes : 0;
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int wave_id = (int)blockIdx.x * WAVES + wave;
 
   bool queue_open = true;
@@ -1562,9 +1561,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             const int n_need = (int)__popcll(need);
             const int avail = c_end - c_next;
             const int take = n_need < avail ? n_need : avail;
-            const int rank = (int)__popcll(need & lane_lt);
+            // set bits of `need` below this lane (v_mbcnt: no lane mask kept in registers)
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             bool valid = false;
-            if (((need >> lane) & 1ull) && rank < take) {
+            if (phase == PH_NEED && !got && rank < take) {
               // k -> (pixel of the row, sample of the chunk), pixel-major: the lanes of a wave stay on a few pixels
               int k = c_next + rank;
               int px = k >> shift;
