@@ -164,6 +164,10 @@ extern f32  rt_kernel_timing_mean_ms(i32 *n_launches);
 /* rt_math.h on the GPU; op codes as oracle_math() (oracle/oracle.h).  Host
  * pointers. */
 extern int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
+/* the leaf blocks' four-instruction reciprocal against IEEE 1.0f / x over all 2^32 bit patterns: out[0] differing patterns
+ * inside its domain (0 expected), out[1] patterns outside the domain, out[2] differing ones among those, out[3] first
+ * differing pattern inside the domain + 1 */
+extern int rt_test_rcp_sweep(u64 out[4]);
 
 /* Closest hit of n rays (host arrays, 6 f32 per ray: origin, direction) against
  * an uploaded scene: out_t[n], out_tri[n] (-1 = miss), out_uv[2n]. */

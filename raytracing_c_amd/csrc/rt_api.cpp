@@ -27,6 +27,7 @@ int rt_launch_resolve(int width, int height, int samples, int chunks_x, const in
 int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, const int32_t *owner_slot,
                      const uint8_t *all_tiles, uint8_t *image, hipStream_t stream);
 int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream);
+int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
                          hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
@@ -168,6 +169,7 @@ struct RT_Device_Scene {
   int32_t      depth = 0, last_row_offset = 0, bg_texture = -1, n_nodes = 0;
   int32_t      n_triangles = 0, n_materials = 0, n_textures = 0;
   int64_t      bytes = 0;
+  float        max_edge = 0.0f;   // largest |component| of an edge b - a, c - a in the leaf tiles (NaN if one is NaN)
   // fingerprint of the host scene this was built from (scene_fingerprint)
   uint64_t     fp = 0;
   // launch state of this device scene: two device scenes can have launches in flight on two streams at once
@@ -473,6 +475,15 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
       e = T.z[2][i] - T.z[0][i]; l[8 * 8 + k] = e;
     }
   }
+  float max_edge = 0.0f;
+  for (int g = 0; g < n_groups; g++) {
+    const float *l = &leaves[(size_t)g * 72];
+    for (int row : {1, 2, 4, 5, 7, 8})
+      for (int k = 0; k < 8; k++) {
+        float m = fabsf(l[row * 8 + k]);
+        if (!(m <= max_edge)) max_edge = m;          // a NaN sticks (every later comparison is false as well)
+      }
+  }
 
   std::vector<float> nodes;
   if (scene->bvh.depth > 0) {
@@ -501,6 +512,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   d->bg_texture = bg;
   d->n_nodes = (int32_t)scene->bvh.nodes.len;
   d->n_triangles = n;
+  d->max_edge = max_edge;
   d->n_materials = (int32_t)(mats.size() / 20);
   d->n_textures = (int32_t)pool.descs.size();
   d->fp = scene_fingerprint(scene);
@@ -884,6 +896,21 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     K.pyr_nodes = K.n_lds_nodes;
     if (const char *e = getenv("RT_PYRAMID")) {
       if (atoi(e) == 0) K.pyr_nodes = 0;
+    }
+    // Leaf blocks with the short reciprocal (rcp_exact, rt_kernels.hip): equal to the IEEE division while every triangle
+    // determinant |e1 . (d x e2)| <= 6 D E^2 stays below 2^102.  E = largest edge component of the scene; D = largest
+    // component of a ray direction: <= 3 max|view matrix entry| for camera rays (the direction is normalised before the
+    // matrix is applied), < 2 for the normalised directions that shading emits.  E <= 2^38 and matrix entries <= 2^16
+    // give 6 D E^2 < 2^97.  Anything else -- or a NaN -- renders with the kernel that divides.
+    float cam_max = 0.0f;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        float m = fabsf(K.cam[i][j]);
+        if (!(m <= cam_max)) cam_max = m;
+      }
+    K.short_div = (d->max_edge <= 0x1p38f && cam_max <= 0x1p16f) ? 1 : 0;
+    if (const char *e = getenv("RT_SHORT_DIV")) {
+      if (atoi(e) == 0) K.short_div = 0;
     }
     if (const char *e = getenv("RT_GRAB")) {
       int v = atoi(e);
@@ -1269,6 +1296,22 @@ extern "C" int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out)
   int rc = rt_launch_test_math(op, n, dx, dy, dout, nullptr);
   if (rc == 0) rc = (int)hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
   if (rc != 0) return rt_fail("rt_test_math failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+// rcp_exact() (the four-instruction reciprocal of the leaf blocks) against the IEEE quotient over all 2^32 bit patterns:
+// out[0] differing patterns inside its domain (must be 0), out[1] patterns outside the domain, out[2] differing ones
+// among those, out[3] first differing pattern inside the domain + 1.
+extern "C" int rt_test_rcp_sweep(u64 out[4]) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (!out) return rt_fail("rt_test_rcp_sweep: NULL");
+  DevBuf b;
+  HIP_TRY(b.alloc(4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(b.p, 0, 4 * sizeof(unsigned long long)));
+  int rc = rt_launch_test_rcp_sweep(b.as<unsigned long long>(), nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out, b.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (rc != 0) return rt_fail("rt_test_rcp_sweep failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 

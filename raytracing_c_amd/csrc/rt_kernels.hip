@@ -192,6 +192,25 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
   return w | ((8u - n_inf) << 24);
 }
 
+// 1 / x in six instructions where hipcc's IEEE division takes eleven (one of them the double-length v_rcp_f32 in both):
+// x is scaled by 2^24 (exact; brings every denormal into the normal range), v_rcp_f32 (1 ulp) is refined by one Newton
+// step with the exact residual (two FMAs), v_div_fixup_f32 restores zero / infinity / NaN, and the quotient is scaled by
+// 2^24 again (exact, or the same overflow to infinity as the division's).  The result EQUALS the correctly rounded 1.0f / x
+// for EVERY x with |x| < 2^102 and for infinity and NaN: all those bit patterns are compared on the GPU against the IEEE
+// sequence (rt_test_rcp_sweep, tests/test_gpu_parity.py).  For 2^102 <= |x| < infinity (quotient below 2^-102, 2^24 x
+// beyond v_rcp_f32's range) it is NOT: callers must exclude such x (RT_SHORT_DIV_MAX_X) or divide.
+#define RT_SHORT_DIV_MAX_X 0x1p102f
+__device__ __forceinline__ float rcp_exact(float x) {
+  float xs = x * 0x1p24f;
+  float y = __builtin_amdgcn_rcpf(xs);
+  float e = __builtin_fmaf(-xs, y, 1.0f);
+  float z = __builtin_fmaf(e, y, y);
+  return __builtin_amdgcn_div_fixupf(z, xs, 1.0f) * 0x1p24f;
+}
+__device__ __forceinline__ bool rcp_exact_outside(float x) {
+  return __builtin_fabsf(x) >= RT_SHORT_DIV_MAX_X && __builtin_fabsf(x) < RT_INF;
+}
+
 // 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32).
 // One triangle: Moeller-Trumbore without determinant test; returns the sanitised distance.
 __device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, float az, float e1x, float e1y, float e1z,
@@ -214,6 +233,48 @@ __device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, flo
   u_out = u;
   v_out = v;
   return (dist > 0.0f) ? dist : RT_INF;          // NaN -> +inf (min_f32x8)
+}
+
+// leaf_test<false>() with 1 / det by rcp_exact(): same bits as long as every |det| < 2^102, which the host guarantees
+// from the scene's edge lengths and the camera matrix before it selects the kernel built on this (rt_api.cpp).
+__device__ __forceinline__ bool leaf_test_short_div(const RT_KParams &P, const Ray3 &r, int g, HitRec &hit) {
+  float best = RT_INF, bu = 0.0f, bv = 0.0f;
+  int   bi = 0;
+  const float *lb = P.leaves + (size_t)g * 72;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    float4 x0 = ld4(lb, 0 + h), x1 = ld4(lb, 2 + h), x2 = ld4(lb, 4 + h);
+    float4 y0 = ld4(lb, 6 + h), y1 = ld4(lb, 8 + h), y2 = ld4(lb, 10 + h);
+    float4 z0 = ld4(lb, 12 + h), z1 = ld4(lb, 14 + h), z2 = ld4(lb, 16 + h);
+    float ax[4] = {x0.x, x0.y, x0.z, x0.w}, bx[4] = {x1.x, x1.y, x1.z, x1.w}, cx[4] = {x2.x, x2.y, x2.z, x2.w};
+    float ay[4] = {y0.x, y0.y, y0.z, y0.w}, by[4] = {y1.x, y1.y, y1.z, y1.w}, cy[4] = {y2.x, y2.y, y2.z, y2.w};
+    float az[4] = {z0.x, z0.y, z0.z, z0.w}, bz[4] = {z1.x, z1.y, z1.z, z1.w}, cz[4] = {z2.x, z2.y, z2.z, z2.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // tri_test() with the other reciprocal; same expression order
+      rt_v3 edge1 = rt_v3_make(bx[k], by[k], bz[k]), edge2 = rt_v3_make(cx[k], cy[k], cz[k]);
+      rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
+      float det = rt_v3_dot(edge1, rxe2);
+      float inv_det = rcp_exact(det);
+      rt_v3 s = rt_v3_sub(r.o, rt_v3_make(ax[k], ay[k], az[k]));
+      rt_v3 sxe1 = rt_v3_cross(s, edge1);
+      float u = inv_det * rt_v3_dot(s, rxe2);
+      float v = inv_det * rt_v3_dot(r.d, sxe1);
+      float t = inv_det * rt_v3_dot(edge2, sxe1);
+      bool miss = (u < -RT_EPS) || (u > 1.0f + RT_EPS) || (v < -RT_EPS) || (u + v > 1.0f + RT_EPS) || (t < RT_EPS);
+      float dist = miss ? RT_INF : t;
+      dist = (dist > 0.0f) ? dist : RT_INF;          // NaN -> +inf (min_f32x8)
+      if (dist < best) { best = dist; bi = h * 4 + k; bu = u; bv = v; }   // lowest lane wins ties
+    }
+  }
+  if (best < hit.t) {
+    hit.t = best;
+    hit.tri = g * 8 + bi;
+    hit.u = bu;
+    hit.v = bv;
+    return true;
+  }
+  return false;
 }
 
 template <bool SCALAR>
@@ -1282,7 +1343,7 @@ struct PrimaryParams {          // what primary_ray reads
 };
 
 
-template <int WAVES, bool LDSN, int MIN_WAVES_PER_SIMD = 1>
+template <int WAVES, bool LDSN, int MIN_WAVES_PER_SIMD, bool SHORT_DIV>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel_stream(RT_KParams P) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
@@ -1638,7 +1699,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           w_leaves += (uint32_t)nL;
           if (phase == PH_LEAF) {
             int  g = child - P.last_row_offset;
-            bool got = leaf_test<false>(P, ray, g, hit);
+            bool got = SHORT_DIV ? leaf_test_short_div(P, ray, g, hit) : leaf_test<false>(P, ray, g, hit);
             if (got) dirty = 0xFFFFFFFFu;
             phase = PH_POP;
           }
@@ -2055,9 +2116,32 @@ __global__ void rt_test_math_kernel(int op, int n, const float *x, const float *
   case 8: r = rt_linear_to_srgb(a); break;
   case 9: r = rt_sqrtf(a); break;
   case 10: r = 1.0f / a; break;
+  case 11: r = rcp_exact(a); break;
+  case 12: r = rcp_exact_outside(a) ? 1.0f : 0.0f; break;
   default: break;
   }
   out[i] = r;
+}
+
+// All 2^32 bit patterns x: rcp_exact(x) against the IEEE quotient 1.0f / x.  counts[0] = patterns inside the claimed
+// domain (|x| < 2^102, infinity, NaN) that differ (NaN equals NaN), counts[1] = patterns outside it, counts[2] = of those,
+// how many differ (why the domain ends there), counts[3] = first differing pattern inside the domain + 1.
+__global__ void rt_test_rcp_sweep_kernel(unsigned long long *counts) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t bad_in = 0, n_out = 0, bad_out = 0, first = 0;
+  for (uint32_t k = 0; k < 256u; k++) {
+    const uint32_t b = tid * 256u + k;
+    const float x = __uint_as_float(b);
+    const uint32_t w = __float_as_uint(1.0f / x), g = __float_as_uint(rcp_exact(x));
+    const bool w_nan = (w & 0x7FFFFFFFu) > 0x7F800000u, g_nan = (g & 0x7FFFFFFFu) > 0x7F800000u;
+    const bool same = w_nan ? g_nan : (g == w);
+    if (rcp_exact_outside(x)) { n_out += 1; bad_out += same ? 0u : 1u; }
+    else if (!same) { bad_in += 1; if (!first) first = b + 1u; }
+  }
+  if (bad_in) atomicAdd(&counts[0], (unsigned long long)bad_in);
+  if (n_out) atomicAdd(&counts[1], (unsigned long long)n_out);
+  if (bad_out) atomicAdd(&counts[2], (unsigned long long)bad_out);
+  if (first) atomicMax(&counts[3], (unsigned long long)first);
 }
 
 __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_test_trace_kernel(RT_KParams P, int n, const float *rays,
@@ -2127,23 +2211,25 @@ extern "C" int rt_launch_stream_init(int n_tiles, uint32_t *tile_next, uint32_t 
   return (int)hipGetLastError();
 }
 
-template <int WAVES, bool LDSN, int MINW>
+template <int WAVES, bool LDSN, int MINW, bool SHORT_DIV>
 static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set && smem_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_stream<WAVES, LDSN, MINW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((rt_path_kernel_stream<WAVES, LDSN, MINW>), dim3((n_waves + WAVES - 1) / WAVES), dim3(WAVES * 64),
-                     smem_bytes, stream, *P);
+  hipLaunchKernelGGL((rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>), dim3((n_waves + WAVES - 1) / WAVES),
+                     dim3(WAVES * 64), smem_bytes, stream, *P);
   return (int)hipGetLastError();
 }
 
 extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
   switch (variant) {
-  case 5: return launch_stream<16, true, 1>(P, n_waves, smem_bytes, stream);
+  case 5:
+    return P->short_div ? launch_stream<16, true, 1, true>(P, n_waves, smem_bytes, stream)
+                        : launch_stream<16, true, 1, false>(P, n_waves, smem_bytes, stream);
   case 1:
     hipLaunchKernelGGL(rt_path_kernel, dim3((n_waves + 3) / 4), dim3(RT_BLOCK_THREADS), 0, stream, *P);
     return (int)hipGetLastError();
@@ -2190,6 +2276,11 @@ extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int height,
 
 extern "C" int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream) {
   hipLaunchKernelGGL(rt_test_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, n, x, y, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_test_rcp_sweep_kernel, dim3(65536), dim3(256), 0, stream, counts);
   return (int)hipGetLastError();
 }
 

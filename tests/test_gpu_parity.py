@@ -61,6 +61,34 @@ def test_math_bit_exact(rt, oracle, op, name, gx, gy):
     assert bad.size == 0, f"{name}: {bad.size} mismatches, first x={x[bad[0]]!r} want={want[bad[0]]!r} got={got[bad[0]]!r}"
 
 
+def test_short_reciprocal_equals_the_division(rt, oracle):
+    """Leaf blocks of the tile-stream kernel take 1 / det from rcp_exact() (v_rcp_f32 + one Newton step, scaled by 2^24
+    on the way in and out) instead of hipcc's IEEE division sequence.  The claim is equality, not accuracy: every bit
+    pattern with |x| < 2^102, both infinities and every NaN is compared on the device with 1.0f / x, and a sample --
+    denormals, zeros, infinities, powers of two, all-ones mantissas -- with the CPU's division (the oracle's)."""
+    from tests import _oracle
+    out = (C.c_uint64 * 4)()
+    assert rt.lib.rt_test_rcp_sweep(out) == 0, rt.last_error()
+    inside_bad, outside_n, outside_bad, first = (int(v) for v in out)
+    assert inside_bad == 0, f"first differing pattern {first - 1:#010x}"
+    assert outside_n == 2 * 26 * (1 << 23)           # 2^102 <= |x| < infinity: exponent fields 229..254, both signs
+    assert outside_bad > 0                            # ... where it really does differ: the host's bound is needed
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 1 << 32, 400000, dtype=np.uint64).astype(np.uint32)
+    special = np.array([0, 0x80000000, 1, 0x007FFFFF, 0x00800000, 0x7F800000, 0xFF800000, 0x7FC00000, 0x3F800000,
+                        0x3FFFFFFF, 0x00FFFFFF, 0x727FFFFF, 0x72800000, 0x807FFFFF, 0x80000001], np.uint32)
+    bits[:special.size] = special
+    bits[special.size:special.size + 50000] &= np.uint32(0x807FFFFF)          # denormals of both signs
+    x = bits.view(np.float32)
+    inside = ~((np.abs(x) >= np.float32(2.0 ** 102)) & np.isfinite(x))
+    want = _oracle.math(10, x, None)
+    got = np.zeros_like(x)
+    assert rt.lib.rt_test_math(11, x.size, x.ctypes.data, None, got.ctypes.data) == 0, rt.last_error()
+    same = (_bits(want) == _bits(got)) | (np.isnan(want) & np.isnan(got))
+    assert same[inside].all(), f"x = {x[inside][~same[inside]][:4]!r}"
+    assert inside.sum() > 300000 and (~inside).sum() > 1000
+
+
 # ---------------------------------------------------------------------------------------
 # traversal + intersection
 
@@ -218,7 +246,7 @@ def test_every_kernel_variant_is_bit_exact(rt, oracle, variant, monkeypatch):
 
 @pytest.mark.parametrize("knobs", [{"RT_SCHED_THRESH": "1"}, {"RT_SCHED_THRESH": "64"}, {"RT_LDS_NODES": "9"},
                                    {"RT_LDS_NODES": "0"}, {"RT_WAVES_PER_CU": "1"}, {"RT_ORDER": "identity"},
-                                   {"RT_GRAB": "1"}, {"RT_GRAB": "4"}, {"RT_DRAIN_THRESH": "1"}, {"RT_PYRAMID": "0"},
+                                   {"RT_GRAB": "1"}, {"RT_GRAB": "4"}, {"RT_DRAIN_THRESH": "1"}, {"RT_PYRAMID": "0"}, {"RT_SHORT_DIV": "0"},
                                    {"RT_KERNEL": "3", "RT_SCHED_THRESH": "16"}])
 def test_scheduling_knobs_do_not_change_the_image(rt, oracle, knobs, monkeypatch):
     """Scheduling is free to change; results are not (order-free fixed-point accumulation)."""
