@@ -198,7 +198,8 @@ def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_na
            "lds": {"node_bytes_per_launch": node_bytes,
                    "rate_GBps": node_bytes / ksec / 1e9 if ksec else None, "peak_GBps": LDS_PEAK_GBS,
                    "frac": node_bytes / ksec / 1e9 / LDS_PEAK_GBS if ksec else None,
-                   "note": "BVH node reads (192 B per node visit) come from the workgroup's LDS copy of the tree"},
+                   "note": "BVH node reads come from the workgroup's LDS copy of the tree; 192 B per node visit is the "
+                           "algorithmic figure and an upper bound: pyramid-culled node blocks read 24 B per surviving child"},
            "l1_l2": {"bytes_per_launch": alg_bytes - node_bytes,
                      "rate_GBps": (alg_bytes - node_bytes) / ksec / 1e9 if ksec else None,
                      "note": "leaf tiles, shading records, texels through L1 / L2"}}
@@ -486,7 +487,7 @@ def main():
         elif args.config == "helmet4k" and (w, h, s, b) == (3840, 2160, 1024, 16):
             workload += " (BASELINE.json configs[4])"
         prof = measured_profile(workload) if world == 1 else None
-        variant = os.environ.get("RT_KERNEL", "5 = rt_path_kernel_stream<16, true>, the default")
+        variant = os.environ.get("RT_KERNEL", "5 = rt_path_kernel_stream<16, true, 1, short reciprocal>, the default")
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
