@@ -168,6 +168,9 @@ extern int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
  * inside its domain (0 expected), out[1] patterns outside the domain, out[2] differing ones among those, out[3] first
  * differing pattern inside the domain + 1 */
 extern int rt_test_rcp_sweep(u64 out[4]);
+/* the kernels' sRGB decode of a texture sample against rt_srgb_to_linear1() for every float in [0, 2] (and 4 M negative ones):
+ * out[0] patterns compared, out[1] differing (0 expected), out[2] first differing pattern + 1 */
+extern int rt_test_srgb_sweep(u64 out[3]);
 
 /* Closest hit of n rays (host arrays, 6 f32 per ray: origin, direction) against
  * an uploaded scene: out_t[n], out_tri[n] (-1 = miss), out_uv[2n]. */

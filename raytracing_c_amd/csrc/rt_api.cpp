@@ -28,6 +28,7 @@ int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, const in
                      const uint8_t *all_tiles, uint8_t *image, hipStream_t stream);
 int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream);
 int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream);
+int rt_launch_test_srgb_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
                          hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
@@ -1312,6 +1313,22 @@ extern "C" int rt_test_rcp_sweep(u64 out[4]) {
   int rc = rt_launch_test_rcp_sweep(b.as<unsigned long long>(), nullptr);
   if (rc == 0) rc = (int)hipMemcpy(out, b.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   if (rc != 0) return rt_fail("rt_test_rcp_sweep failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+// The kernels' sRGB decode of a texture sample (division by 1.055 as a corrected multiplication) against
+// rt_srgb_to_linear1() for every float in [0, 2] (and 4 M negative ones): out[0] patterns compared, out[1] differing (0 expected),
+// out[2] first differing pattern + 1.
+extern "C" int rt_test_srgb_sweep(u64 out[3]) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (!out) return rt_fail("rt_test_srgb_sweep: NULL");
+  DevBuf b;
+  HIP_TRY(b.alloc(3 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(b.p, 0, 3 * sizeof(unsigned long long)));
+  int rc = rt_launch_test_srgb_sweep(b.as<unsigned long long>(), nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out, b.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (rc != 0) return rt_fail("rt_test_srgb_sweep failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 

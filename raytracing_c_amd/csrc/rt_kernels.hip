@@ -420,6 +420,25 @@ __device__ __forceinline__ rt_v3 tex_bilinear(const PT &P, int tex, float tx, fl
   return rt_v3_lerp(c0, c1, b);
 }
 
+// rt_srgb_to_linear() of a bilinear texture sample: (x + 0.055f) / 1.055f as a multiplication by RN(1 / 1.055f) corrected
+// with the exact residual (two FMAs) -- 3 instructions where the IEEE division takes 11.  The corrected quotient equals
+// the division for every a = x + 0.055f with 2^-104 <= |a| < infinity and for NaN (tools/exp/div_test.hip, all 2^32 a);
+// rt_test_srgb_sweep compares every x in [0, 2] -- 1.07 G bit patterns -- with rt_srgb_to_linear1().  A texture sample is a
+// lerp of u8 / 255.999 values, 0 <= x <= 0.9961, or NaN for NaN texture coordinates.  Same rt_powf() afterwards.
+__device__ __forceinline__ float srgb_to_linear_tex1(float x) {
+#ifdef RT_EXP_SRGB_IEEE
+  return rt_srgb_to_linear1(x);
+#endif
+  const float c = 1.0f / 1.055f;
+  float a = x + 0.055f;
+  float q = a * c;
+  float r = __builtin_fmaf(-1.055f, q, a);
+  return rt_powf(__builtin_fmaf(r, c, q), 2.4f);
+}
+__device__ __forceinline__ rt_v3 srgb_to_linear_tex(rt_v3 v) {
+  return rt_v3_make(srgb_to_linear_tex1(v.x), srgb_to_linear_tex1(v.y), srgb_to_linear_tex1(v.z));
+}
+
 // driver.c:95-104
 template <class PT>
 __device__ __forceinline__ rt_v3 background_lookup(const PT &P, rt_v3 dir) {
@@ -427,7 +446,7 @@ __device__ __forceinline__ rt_v3 background_lookup(const PT &P, rt_v3 dir) {
   float inv_two_pi = 1.0f / (2.0f * RT_PI);
   float u = 0.5f + rt_atan2f(dir.z, dir.x) * inv_two_pi;
   float v = 0.5f - rt_asinf(dir.y) * inv_pi;
-  return rt_srgb_to_linear(tex_bilinear(P, P.bg_texture, u, v));
+  return srgb_to_linear_tex(tex_bilinear(P, P.bg_texture, u, v));
 }
 
 // ---------------------------------------------------------------------------------
@@ -585,7 +604,7 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   if (tex_albedo >= 0 || tex_normal >= 0 || tex_mr >= 0 || tex_em >= 0) cn.textured += 1;
 
   rt_v3 base_color = rt_v3_make(m0.x, m0.y, m0.z);
-  if (tex_albedo >= 0) base_color = rt_v3_mul(base_color, rt_srgb_to_linear(tex_bilinear(P, tex_albedo, in.uvx, in.uvy)));
+  if (tex_albedo >= 0) base_color = rt_v3_mul(base_color, srgb_to_linear_tex(tex_bilinear(P, tex_albedo, in.uvx, in.uvy)));
 
   float roughness = m0.w, metalness = m1.w;
   if (tex_mr >= 0) {
@@ -598,7 +617,7 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   metalness /= 0.9f;
 
   emission = rt_v3_make(m1.x, m1.y, m1.z);
-  if (tex_em >= 0) emission = rt_v3_mul(emission, rt_srgb_to_linear(tex_bilinear(P, tex_em, in.uvx, in.uvy)));
+  if (tex_em >= 0) emission = rt_v3_mul(emission, srgb_to_linear_tex(tex_bilinear(P, tex_em, in.uvx, in.uvy)));
 
   // basis(), driver.c:155-164
   rt_v3 t, b;
@@ -2118,6 +2137,7 @@ __global__ void rt_test_math_kernel(int op, int n, const float *x, const float *
   case 10: r = 1.0f / a; break;
   case 11: r = rcp_exact(a); break;
   case 12: r = rcp_exact_outside(a) ? 1.0f : 0.0f; break;
+  case 13: r = srgb_to_linear_tex1(a); break;
   default: break;
   }
   out[i] = r;
@@ -2142,6 +2162,24 @@ __global__ void rt_test_rcp_sweep_kernel(unsigned long long *counts) {
   if (n_out) atomicAdd(&counts[1], (unsigned long long)n_out);
   if (bad_out) atomicAdd(&counts[2], (unsigned long long)bad_out);
   if (first) atomicMax(&counts[3], (unsigned long long)first);
+}
+
+// srgb_to_linear_tex1(x) against rt_srgb_to_linear1(x) for every float in [0, 2] and in [-0.046875, -0.03125]: counts[0] =
+// patterns compared (2^30 + 2^22), counts[1] = patterns that differ, counts[2] = first differing pattern + 1.
+__global__ void rt_test_srgb_sweep_kernel(unsigned long long *counts) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;       // 2^22 threads x 256 patterns = [0, 0x40000000)
+  uint32_t n = 0, bad = 0, first = 0;
+  for (uint32_t k = 0; k < 257u; k++) {
+    uint32_t b = tid * 256u + k;
+    if (k == 256u) b = tid == 0 ? 0x40000000u : 0xBD000000u + tid - 1u;        // 2.0, and 2^22 - 1 negative values from -0.03125 down
+    const float x = __uint_as_float(b);
+    const uint32_t w = __float_as_uint(rt_srgb_to_linear1(x)), g = __float_as_uint(srgb_to_linear_tex1(x));
+    n += 1;
+    if (w != g) { bad += 1; if (!first) first = b + 1u; }
+  }
+  atomicAdd(&counts[0], (unsigned long long)n);
+  if (bad) atomicAdd(&counts[1], (unsigned long long)bad);
+  if (first) atomicMax(&counts[2], (unsigned long long)first);
 }
 
 __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_test_trace_kernel(RT_KParams P, int n, const float *rays,
@@ -2281,6 +2319,11 @@ extern "C" int rt_launch_test_math(int op, int n, const float *x, const float *y
 
 extern "C" int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream) {
   hipLaunchKernelGGL(rt_test_rcp_sweep_kernel, dim3(65536), dim3(256), 0, stream, counts);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_test_srgb_sweep(unsigned long long *counts, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_test_srgb_sweep_kernel, dim3(16384), dim3(256), 0, stream, counts);
   return (int)hipGetLastError();
 }
 

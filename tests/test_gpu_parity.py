@@ -89,6 +89,24 @@ def test_short_reciprocal_equals_the_division(rt, oracle):
     assert inside.sum() > 300000 and (~inside).sum() > 1000
 
 
+def test_texture_srgb_decode_equals_the_division(rt, oracle):
+    """The kernels decode a texture sample with (x + 0.055f) * RN(1 / 1.055f) corrected by the exact residual instead of the
+    division by 1.055f of common.h:84-91.  Every float in [0, 2] and in [-0.046875, -0.03125] -- a sample lies in [0, 0.9961] --
+    gives the same bits as rt_srgb_to_linear1() on the device; a sample of them is compared with the CPU's."""
+    from tests import _oracle
+    out = (C.c_uint64 * 3)()
+    assert rt.lib.rt_test_srgb_sweep(out) == 0, rt.last_error()
+    n, bad, first = (int(v) for v in out)
+    assert n == (1 << 30) + (1 << 22)
+    assert bad == 0, f"first differing pattern {first - 1:#010x}"
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(0, 1, 200000), rng.uniform(0, 1e-6, 1000), [0.0, 1.0, 0.9961, np.nan]]).astype(np.float32)
+    want = _oracle.math(7, x, None)
+    got = np.zeros_like(x)
+    assert rt.lib.rt_test_math(13, x.size, x.ctypes.data, None, got.ctypes.data) == 0, rt.last_error()
+    assert np.array_equal(_bits(want)[:-1], _bits(got)[:-1]) and np.isnan(got[-1]) == np.isnan(want[-1])
+
+
 # ---------------------------------------------------------------------------------------
 # traversal + intersection
 
