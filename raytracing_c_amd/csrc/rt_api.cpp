@@ -178,6 +178,8 @@ struct RT_Device_Scene {
   uint32_t           *work_head = nullptr;
   uint32_t           *tile_next = nullptr;     // tile-stream kernel: chunks handed out per tile
   int32_t             tile_next_n = 0;
+  uint32_t           *park = nullptr;          // tile-stream kernel: parked hits, [waves][18][128]
+  int32_t             park_waves = 0;
   // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
   uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
   uint32_t    *order = nullptr, *hist = nullptr;
@@ -200,6 +202,7 @@ static void free_device_scene(RT_Device_Scene *d) {
   (void)hipFree(d->counters);
   (void)hipFree(d->work_head);
   (void)hipFree(d->tile_next);
+  (void)hipFree(d->park);
   (void)hipFree(d->cost[0]);
   (void)hipFree(d->cost[1]);
   (void)hipFree(d->order);
@@ -916,6 +919,20 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     if (const char *e = getenv("RT_GRAB")) {
       int v = atoi(e);
       if (v == 1 || v == 2 || v == 4) K.grab_max = v;
+    }
+    // hits parked until a dense shade block can be made of them: 18 x 128 dwords per wave (RT_PARK=0: shade at once)
+    K.park = nullptr;
+    const char *park_env = getenv("RT_PARK");
+    if (!(park_env && atoi(park_env) == 0)) {
+      const int grid_waves = (n_waves + 15) / 16 * 16;         // whole workgroups of 16 waves are launched
+      if (d->park_waves < grid_waves) {
+        (void)hipFree(d->park);
+        d->park = nullptr;
+        d->park_waves = 0;
+        HIP_TRY(hipMalloc(&d->park, (size_t)grid_waves * 18 * 128 * 4));
+        d->park_waves = grid_waves;
+      }
+      K.park = d->park;
     }
   }
 

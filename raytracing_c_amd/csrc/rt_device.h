@@ -99,6 +99,7 @@ typedef struct {
   int32_t n_sample_blocks;     /* ceil(samples of this launch / samples per unit)                           */
   int32_t drain_thresh;        /* lanes waiting for S that trigger it once the wave's tile is exhausted     */
   int32_t grab_max;            /* units a wave takes per atomic while its tile has plenty left (1, 2 or 4)   */
+  uint32_t *park;              /* tile-stream kernel: [waves][18][128] dwords, hits parked until a dense shade block (nullptr = off) */
   int32_t short_div;           /* 1: leaf blocks take 1 / det from rcp_exact() (host-checked determinant bound), 0: IEEE division */
   int32_t pyr_nodes;           /* node blocks of camera rays on nodes [0, n) test only the children the tile's pyramid can touch; 0 = off */
 } RT_KParams;

@@ -1241,6 +1241,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 //  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
+#define RT_PARK_FIELDS 18     // hit (t, triangle, u, v), ray origin and direction, tint, emission, rng, pixel | bounce << 16
+#define RT_PARK_CAP 128       // parked hits per wave (fewer than RT_PARK_DENSE + 64 are ever parked)
+#ifndef RT_PARK_DENSE
+#define RT_PARK_DENSE 56      // lanes that make a shade block worth running while the tile still hands out paths
+#endif
 #ifndef RT_PYR_NUM
 #define RT_PYR_NUM 3       // a pyramid-culled node block needs nG >= nN * RT_PYR_NUM / RT_PYR_DEN camera rays on one node
 #define RT_PYR_DEN 4
@@ -1562,6 +1567,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     int  c_next = 0, c_end = 0, c_x0 = 0, c_y = 0, c_pix0 = 0, c_s0 = 0;
     uint32_t u_cur = 0, u_end = 0, grab = queue_open ? (uint32_t)cold_args()->grab_max : 1u;
     bool took_any = false;
+    int  n_parked = 0;                   // hits of this tile waiting in the wave's slice of `park`
+    uint32_t *park = cold_args()->park;
 
     for (;;) {
       // ================= S: shade the hits, environment for the misses, start new paths =================
@@ -1575,14 +1582,75 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         ShadeParams SP;
         SP.tris = A->tris; SP.mats = A->mats; SP.textures = A->textures; SP.texels = A->texels;
         SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
-        if (phase == PH_HIT) {
-          done = shade_hit(SP, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
-          start = !done;
-        } else if (phase == PH_MISS) {
+        // ---- environment for the paths that left the scene ----
+        if (phase == PH_MISS) {
           cn.bgs = 1;
           rt_v3 bg = background_lookup(SP, dir);
           radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
           done = true;
+        }
+        // ---- hits: shade them now, or park them until a dense shade block can be made of them ----
+        // A shade block costs ~2 200 instructions whatever the number of lanes in it, and hits arrive ~34 at a time.  While
+        // the tile still hands out paths, the hits of a sparse S block are PARKED (18 dwords of path state per hit into the
+        // wave's slice of `park`, struct-of-arrays: every store is one 256-byte line) and their lanes start new camera
+        // paths; once the hits at hand plus the parked ones that fit into idle lanes make RT_PARK_DENSE lanes, the parked
+        // ones come back into idle lanes and all are shaded in one block.  A draining tile shades what it has.  Which
+        // wave-iteration shades a path does not matter: its state (rng included) travels with it, sums are order-free.
+        bool shade_now = true;
+        if (park) {
+          const unsigned long long mHit = __ballot(phase == PH_HIT);
+          const unsigned long long mIdle = __ballot(phase == PH_NEED) | __ballot(phase == PH_MISS);
+          const int h = (int)__popcll(mHit), f = (int)__popcll(mIdle);
+          const int back = n_parked < f ? n_parked : f;                 // parked hits that fit into idle lanes
+          uint32_t *pk = park + (size_t)wave_id * (RT_PARK_FIELDS * RT_PARK_CAP);
+          if (!tile_open || h + back >= RT_PARK_DENSE || n_parked + h > RT_PARK_CAP) {
+            if (back > 0) {
+              if (done) {                                               // (an environment lane is idle once its sample is added)
+                unsigned long long *ap = reinterpret_cast<unsigned long long *>(lds_at(smem, acc_off) + pix * 6);
+                atomicAdd(ap + 0, (unsigned long long)rt_accum_quantize(radiance.x));
+                atomicAdd(ap + 1, (unsigned long long)rt_accum_quantize(radiance.y));
+                atomicAdd(ap + 2, (unsigned long long)rt_accum_quantize(radiance.z));
+                phase = PH_NEED;
+                done = false;
+              }
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mIdle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mIdle, 0u));
+              if (phase == PH_NEED && rank < back) {
+                const uint32_t *q = pk + (n_parked - 1 - rank);         // most recently parked first
+                uint32_t v[RT_PARK_FIELDS];
+#pragma unroll
+                for (int i = 0; i < RT_PARK_FIELDS; i++)
+                  v[i] = __hip_atomic_load(q + i * RT_PARK_CAP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hit.t = as_f((int)v[0]); hit.tri = (int)v[1]; hit.u = as_f((int)v[2]); hit.v = as_f((int)v[3]);
+                org = rt_v3_make(as_f((int)v[4]), as_f((int)v[5]), as_f((int)v[6]));
+                dir = rt_v3_make(as_f((int)v[7]), as_f((int)v[8]), as_f((int)v[9]));
+                tint = rt_v3_make(as_f((int)v[10]), as_f((int)v[11]), as_f((int)v[12]));
+                emis = rt_v3_make(as_f((int)v[13]), as_f((int)v[14]), as_f((int)v[15]));
+                rng = v[16]; pix = (int)(v[17] & 0xFFFFu); bounce = (int)(v[17] >> 16);
+                phase = PH_HIT;
+              }
+              n_parked -= back;
+            }
+          } else if (h > 0) {
+            shade_now = false;
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mHit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mHit, 0u));
+            if (phase == PH_HIT) {
+              uint32_t *q = pk + (n_parked + rank);
+              const uint32_t v[RT_PARK_FIELDS] = {(uint32_t)as_i(hit.t), (uint32_t)hit.tri, (uint32_t)as_i(hit.u), (uint32_t)as_i(hit.v),
+                                                  (uint32_t)as_i(org.x), (uint32_t)as_i(org.y), (uint32_t)as_i(org.z),
+                                                  (uint32_t)as_i(dir.x), (uint32_t)as_i(dir.y), (uint32_t)as_i(dir.z),
+                                                  (uint32_t)as_i(tint.x), (uint32_t)as_i(tint.y), (uint32_t)as_i(tint.z),
+                                                  (uint32_t)as_i(emis.x), (uint32_t)as_i(emis.y), (uint32_t)as_i(emis.z),
+                                                  rng, (uint32_t)pix | ((uint32_t)bounce << 16)};
+#pragma unroll
+              for (int i = 0; i < RT_PARK_FIELDS; i++) q[i * RT_PARK_CAP] = v[i];
+              phase = PH_NEED;
+            }
+            n_parked += h;
+          }
+        }
+        if (phase == PH_HIT && shade_now) {
+          done = shade_hit(SP, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
+          start = !done;
         }
         if (done) {
           // (32-bit address arithmetic from the wave's byte offset: `acc + pix * 3` is a 64-bit multiply-add on a pointer
@@ -1699,6 +1767,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       const int n_trav0 = (int)__popcll(__ballot(phase == PH_NODE || phase == PH_LEAF));
       if (n_trav0 == 0) {
         if (__any(phase == PH_MISS)) continue;   // camera rays that skipped the root: straight to the environment
+        if (n_parked > 0 || __any(phase == PH_HIT)) continue;      // parked hits come back in the next S block
         if (!tile_open) break;            // every path of the tile that this wave took has ended
         continue;                         // (nothing started, e.g. pixels outside the image: pull more)
       }
