@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 #define RT_PARK_FIELDS 18     // hit (t, triangle, u, v), ray origin and direction, tint, emission, rng, pixel | bounce << 16
 #define RT_PARK_CAP 128       // parked hits per wave (fewer than RT_PARK_DENSE + 64 are ever parked)
 #ifndef RT_PARK_DENSE
-#define RT_PARK_DENSE 56      // lanes that make a shade block worth running while the tile still hands out paths
+#define RT_PARK_DENSE 48      // lanes that make a shade block worth running while the tile still hands out paths
 #endif
 #ifndef RT_PYR_NUM
 #define RT_PYR_NUM 3       // a pyramid-culled node block needs nG >= nN * RT_PYR_NUM / RT_PYR_DEN camera rays on one node
