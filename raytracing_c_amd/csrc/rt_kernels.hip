@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           const unsigned long long mIdle = __ballot(phase == PH_NEED) | __ballot(phase == PH_MISS);
           const int h = (int)__popcll(mHit), f = (int)__popcll(mIdle);
           const int back = n_parked < f ? n_parked : f;                 // parked hits that fit into idle lanes
-          uint32_t *pk = park + (size_t)wave_id * (RT_PARK_FIELDS * RT_PARK_CAP);
+          uint32_t *pk = park + (size_t)__builtin_amdgcn_readfirstlane(wave_id) * (RT_PARK_FIELDS * RT_PARK_CAP);    // (scalar base)
           if (!tile_open || h + back >= RT_PARK_DENSE || n_parked + h > RT_PARK_CAP) {
             if (back > 0) {
               if (done) {                                               // (an environment lane is idle once its sample is added)

@@ -264,7 +264,7 @@ def test_every_kernel_variant_is_bit_exact(rt, oracle, variant, monkeypatch):
 
 @pytest.mark.parametrize("knobs", [{"RT_SCHED_THRESH": "1"}, {"RT_SCHED_THRESH": "64"}, {"RT_LDS_NODES": "9"},
                                    {"RT_LDS_NODES": "0"}, {"RT_WAVES_PER_CU": "1"}, {"RT_ORDER": "identity"},
-                                   {"RT_GRAB": "1"}, {"RT_GRAB": "4"}, {"RT_DRAIN_THRESH": "1"}, {"RT_PYRAMID": "0"}, {"RT_SHORT_DIV": "0"},
+                                   {"RT_GRAB": "1"}, {"RT_GRAB": "4"}, {"RT_DRAIN_THRESH": "1"}, {"RT_PYRAMID": "0"}, {"RT_SHORT_DIV": "0"}, {"RT_PARK": "0"},
                                    {"RT_KERNEL": "3", "RT_SCHED_THRESH": "16"}])
 def test_scheduling_knobs_do_not_change_the_image(rt, oracle, knobs, monkeypatch):
     """Scheduling is free to change; results are not (order-free fixed-point accumulation)."""
