@@ -1237,7 +1237,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 //    waves.  Every unit is handed out exactly once by an atomic; radiance sums are order-free integers, so results do
 //    not depend on who traced what.  Owners always finish their tile, so a joiner may give up at any time: every wave
 //    reaches an exit (bounded scans), there is no inter-wave dependency and no grid barrier.
-//  * Camera rays of a tile whose pixel pyramid misses every child box of the root skip the root block (below).
+//  * Camera rays of a tile whose pixel pyramid misses every child box of the root skip the root block (below); node blocks
+//    whose lanes are (mostly) camera rays about to enter ONE node test only the child boxes that pyramid can touch
+//    (pyramid_cull_mask, node_enter_few; the mask of a (tile, node) is cached in LDS).
+//  * Hits are parked -- path state to memory, lane to a new path -- while a shade block would run sparse, and shaded
+//    together when 48 lanes can be filled (`park`, S block).
 //  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
