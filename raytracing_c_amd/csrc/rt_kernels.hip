@@ -667,7 +667,8 @@ __device__ __forceinline__ void primary_ray(const PT &P, int x, int y, int sampl
   float uvx = ((float)x + jitter - 0.5f) * 2.0f * inv_width - 1.0f;
   float uvy = ((float)y + jitter - 0.5f) * 2.0f * inv_height - 1.0f;
   float dx = uvx * aspect, dy = -uvy, dz = -P.focal_length;
-  float inv_length = 1.0f / rt_sqrtf(dx * dx + dy * dy + dz * dz);
+  // (rcp_exact: a square root lies in [0, 2^64] or is infinite / NaN -- inside the domain on which it equals the division)
+  float inv_length = rcp_exact(rt_sqrtf(dx * dx + dy * dy + dz * dz));
   float rx = P.cam[0][0] * dx + P.cam[0][1] * dy + P.cam[0][2] * dz;
   float ry = P.cam[1][0] * dx + P.cam[1][1] * dy + P.cam[1][2] * dz;
   float rz = P.cam[2][0] * dx + P.cam[2][1] * dy + P.cam[2][2] * dz;
@@ -675,12 +676,23 @@ __device__ __forceinline__ void primary_ray(const PT &P, int x, int y, int sampl
   d = rt_v3_make(rx * inv_length, ry * inv_length, rz * inv_length);
 }
 
+// SHORT_DIV: the reciprocals by rcp_exact() -- same bits as the division for |component| < 2^102, infinity and NaN.  The
+// tile-stream kernel uses it where the host has bounded the camera matrix (rt_api.cpp): a camera direction is a unit
+// vector through that matrix, every other direction comes out of shade() as t o.x + b o.y + n o.z of normalised vectors
+// (components within +-3.1, or infinite / NaN when a normalisation met a zero or non-finite vector).
+template <bool SHORT_DIV = false>
 __device__ __forceinline__ void ray_setup(Ray3 &r, rt_v3 o, rt_v3 d) {
   r.o = o;
   r.d = d;
-  r.inv_x = 1.0f / d.x;       // raytracer.c:198-202
-  r.inv_y = 1.0f / d.y;
-  r.inv_z = 1.0f / d.z;
+  if (SHORT_DIV) {
+    r.inv_x = rcp_exact(d.x);
+    r.inv_y = rcp_exact(d.y);
+    r.inv_z = rcp_exact(d.z);
+  } else {
+    r.inv_x = 1.0f / d.x;       // raytracer.c:198-202
+    r.inv_y = 1.0f / d.y;
+    r.inv_z = 1.0f / d.z;
+  }
   r.fast = (rt_absf(r.inv_x) < RT_INF) && (rt_absf(r.inv_y) < RT_INF) && (rt_absf(r.inv_z) < RT_INF) &&
            (rt_absf(o.x) < RT_INF) && (rt_absf(o.y) < RT_INF) && (rt_absf(o.z) < RT_INF);
 }
@@ -1751,7 +1763,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         }
         bool skip_root = false;
         if (start) {                      // a new ray: traversal starts at the root (or at leaf group 0)
-          ray_setup(ray, org, dir);
+          ray_setup<SHORT_DIV>(ray, org, dir);
           hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
           dirty = 0;
           live = 0;
