@@ -211,6 +211,10 @@ __device__ __forceinline__ bool rcp_exact_outside(float x) {
   return __builtin_fabsf(x) >= RT_SHORT_DIV_MAX_X && __builtin_fabsf(x) < RT_INF;
 }
 
+// rt_v3_normalize() (rt_math.h: v * (1 / sqrt(v.v))) with the reciprocal from rcp_exact(): a square root lies in [0, 2^64] or
+// is infinite / NaN, inside the domain on which rcp_exact() equals the division -- same bits, 5 instructions fewer.
+__device__ __forceinline__ rt_v3 normalize_dev(rt_v3 v) { return rt_v3_scale(v, rcp_exact(rt_sqrtf(rt_v3_dot(v, v)))); }
+
 // 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32).
 // One triangle: Moeller-Trumbore without determinant test; returns the sanitised distance.
 __device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, float az, float e1x, float e1y, float e1z,
@@ -476,9 +480,9 @@ __device__ __forceinline__ rt_v3 cosine_hemisphere(uint32_t &rng) {           //
 }
 
 __device__ __forceinline__ rt_v3 ggx_vndf(rt_v3 V, float ax, float ay, uint32_t &rng) {  // driver.c:230-250
-  rt_v3 Vh = rt_v3_normalize(rt_v3_make(ax * V.x, ay * V.y, V.z));
+  rt_v3 Vh = normalize_dev(rt_v3_make(ax * V.x, ay * V.y, V.z));
   float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-  rt_v3 T1 = lensq > 0.0f ? rt_v3_scale(rt_v3_make(-Vh.y, Vh.x, 0.0f), 1.0f / rt_sqrtf(lensq)) : rt_v3_make(1, 0, 0);
+  rt_v3 T1 = lensq > 0.0f ? rt_v3_scale(rt_v3_make(-Vh.y, Vh.x, 0.0f), rcp_exact(rt_sqrtf(lensq))) : rt_v3_make(1, 0, 0);
   rt_v3 T2 = rt_v3_cross(Vh, T1);
   float r = rt_sqrtf(rt_rand_f32(&rng));
   float phi = 2.0f * RT_PI * rt_rand_f32(&rng);
@@ -490,7 +494,7 @@ __device__ __forceinline__ rt_v3 ggx_vndf(rt_v3 V, float ax, float ay, uint32_t 
   t2 = (1.0f - s) * rt_sqrtf(1.0f - t1 * t1) + s * t2;
   rt_v3 Nh = rt_v3_add(rt_v3_add(rt_v3_scale(T1, t1), rt_v3_scale(T2, t2)),
                        rt_v3_scale(Vh, rt_sqrtf(rt_max_ps(0.0f, 1.0f - t1 * t1 - t2 * t2))));
-  return rt_v3_normalize(rt_v3_make(ax * Nh.x, ay * Nh.y, rt_max_ps(0.0f, Nh.z)));
+  return normalize_dev(rt_v3_make(ax * Nh.x, ay * Nh.y, rt_max_ps(0.0f, Nh.z)));
 }
 
 struct BrdfIn {
@@ -521,7 +525,7 @@ __device__ __forceinline__ void sample_disney(const BrdfIn &m, rt_v3 in_dir, uin
   out_dir = rt_v3_make(0, 0, 0);
   if (rt_rand_f32(&rng) < dw) {
     out_dir = cosine_hemisphere(rng);
-    micro = rt_v3_normalize(rt_v3_add(out_dir, in_dir));
+    micro = normalize_dev(rt_v3_add(out_dir, in_dir));
     float NoL = out_dir.z, NoV = in_dir.z;
     if (NoL <= 0.0f || NoV <= 0.0f) return;
     float LoH = rt_v3_dot(out_dir, micro);
@@ -555,7 +559,7 @@ __device__ __forceinline__ void sample_disney(const BrdfIn &m, rt_v3 in_dir, uin
     brdf_rgb = rt_v3_make(spec.x * NoL, spec.y * NoL, spec.z * NoL);
     brdf_a = sw * pdf;
   }
-  out_dir = rt_v3_normalize(out_dir);
+  out_dir = normalize_dev(out_dir);
 }
 
 struct ShadeIn {
@@ -573,7 +577,7 @@ __device__ __forceinline__ rt_v3 normal_map(const PT &P, int tex, float strength
     v.y *= -1.0f;
     rt_v3 t = in.tangent, b = in.bitangent, n = in.normal;
     float s = strength;
-    normal = rt_v3_normalize(rt_v3_make(s * (v.x * t.x + v.y * b.x + v.z * n.x) + n.x * (1.0f - s),
+    normal = normalize_dev(rt_v3_make(s * (v.x * t.x + v.y * b.x + v.z * n.x) + n.x * (1.0f - s),
                                         s * (v.x * t.y + v.y * b.y + v.z * n.y) + n.y * (1.0f - s),
                                         s * (v.x * t.z + v.y * b.z + v.z * n.z) + n.z * (1.0f - s)));
   }
@@ -622,11 +626,11 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   // basis(), driver.c:155-164
   rt_v3 t, b;
   if (rt_absf(rt_v3_dot(normal, in.direction)) < 0.9999f) {
-    t = rt_v3_normalize(rt_v3_cross(normal, in.direction));
+    t = normalize_dev(rt_v3_cross(normal, in.direction));
   } else if (rt_absf(rt_v3_dot(normal, rt_v3_make(0, 1, 0))) < 0.9999f) {
-    t = rt_v3_normalize(rt_v3_cross(normal, rt_v3_make(0, 1, 0)));
+    t = normalize_dev(rt_v3_cross(normal, rt_v3_make(0, 1, 0)));
   } else {
-    t = rt_v3_normalize(rt_v3_cross(normal, rt_v3_make(1, 0, 0)));
+    t = normalize_dev(rt_v3_cross(normal, rt_v3_make(1, 0, 0)));
   }
   b = rt_v3_cross(normal, t);
 
@@ -726,7 +730,7 @@ __device__ __forceinline__ bool shade_hit(const PT &P, const HitRec &hit, rt_v3 
   } else {
     ShadeIn in;
     in.direction = dir;
-    in.normal = rt_v3_normalize(n_int);
+    in.normal = normalize_dev(n_int);
     in.tangent = rt_v3_make(q4.x, q4.y, q4.z);
     in.bitangent = rt_v3_make(q5.x, q5.y, q5.z);
     in.uvx = q1.w * t0 + q3.w * t1 + q5.w * t2;
