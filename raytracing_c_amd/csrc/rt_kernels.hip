@@ -1266,6 +1266,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 #ifndef RT_PARK_DENSE
 #define RT_PARK_DENSE 48      // lanes that make a shade block worth running while the tile still hands out paths
 #endif
+#ifndef RT_JOIN_CHOICES
+#define RT_JOIN_CHOICES 4    // random open tiles a joining wave looks at; it takes the one with most units left
+#endif
 #ifndef RT_PYR_NUM
 #define RT_PYR_NUM 3       // a pyramid-culled node block needs nG >= nN * RT_PYR_NUM / RT_PYR_DEN camera rays on one node
 #define RT_PYR_DEN 4
@@ -1480,10 +1483,21 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           if (cand < n_tiles) taken = __hip_atomic_load(&tile_next[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           unsigned long long open = __ballot(taken < n_chunks_tile);
           if (open) {
-            int nt = (int)((hsh >> 12) % (uint32_t)__popcll(open));
-            unsigned long long mm = open;
-            for (int k = 0; k < nt; k++) mm &= mm - 1ull;
-            tile_idx = cand - lane + (int)__builtin_ctzll(mm);
+            // two random open tiles of the group, the one with more units left: fewer, longer joins (every join ends with
+            // a drain of the paths in flight)
+            const int n_open_tiles = (int)__popcll(open);
+            int best = 0;
+            uint32_t best_taken = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < RT_JOIN_CHOICES; c++) {
+              int nt = (int)(((hsh >> 12) * (uint32_t)(2 * c + 1) + (uint32_t)c * 7u) % (uint32_t)n_open_tiles);
+              unsigned long long mm = open;
+              for (int k = 0; k < nt; k++) mm &= mm - 1ull;
+              const int pk_lane = (int)__builtin_ctzll(mm);
+              const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)taken, pk_lane);
+              if (tk < best_taken) { best_taken = tk; best = pk_lane; }
+            }
+            tile_idx = cand - lane + best;
           }
         }
       }
