@@ -923,7 +923,7 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     // hits parked until a dense shade block can be made of them: 18 x 128 dwords per wave (RT_PARK=0: shade at once)
     K.park = nullptr;
     const char *park_env = getenv("RT_PARK");
-    if (!(park_env && atoi(park_env) == 0)) {
+    if (!(park_env && atoi(park_env) == 0) && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
       const int grid_waves = (n_waves + 15) / 16 * 16;         // whole workgroups of 16 waves are launched
       if (d->park_waves < grid_waves) {
         (void)hipFree(d->park);

@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 //  * The traversal blocks run in an inner loop of their own; shading / environment / regeneration run in the outer
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
-#define RT_PARK_FIELDS 18     // hit (t, triangle, u, v), ray origin and direction, tint, emission, rng, pixel | bounce << 16
+#define RT_PARK_FIELDS 18     // hit (t, triangle, u, v), ray origin and direction, tint, emission, rng, pixel of the tile | bounce << 6
 #define RT_PARK_CAP 128       // parked hits per wave (fewer than RT_PARK_DENSE + 64 are ever parked)
 #ifndef RT_PARK_DENSE
 #define RT_PARK_DENSE 48      // lanes that make a shade block worth running while the tile still hands out paths
@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                 dir = rt_v3_make(as_f((int)v[7]), as_f((int)v[8]), as_f((int)v[9]));
                 tint = rt_v3_make(as_f((int)v[10]), as_f((int)v[11]), as_f((int)v[12]));
                 emis = rt_v3_make(as_f((int)v[13]), as_f((int)v[14]), as_f((int)v[15]));
-                rng = v[16]; pix = (int)(v[17] & 0xFFFFu); bounce = (int)(v[17] >> 16);
+                rng = v[16]; pix = (int)(v[17] & 63u); bounce = (int)(v[17] >> 6);
                 phase = PH_HIT;
               }
               n_parked -= back;
@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                                                   (uint32_t)as_i(dir.x), (uint32_t)as_i(dir.y), (uint32_t)as_i(dir.z),
                                                   (uint32_t)as_i(tint.x), (uint32_t)as_i(tint.y), (uint32_t)as_i(tint.z),
                                                   (uint32_t)as_i(emis.x), (uint32_t)as_i(emis.y), (uint32_t)as_i(emis.z),
-                                                  rng, (uint32_t)pix | ((uint32_t)bounce << 16)};
+                                                  rng, (uint32_t)pix | ((uint32_t)bounce << 6)};
 #pragma unroll
               for (int i = 0; i < RT_PARK_FIELDS; i++) q[i * RT_PARK_CAP] = v[i];
               phase = PH_NEED;

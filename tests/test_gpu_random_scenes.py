@@ -189,3 +189,21 @@ def test_scene_scale_selects_the_division(oracle, scale):
         assert want["counters"][k] == getattr(c, k), k
     if scale >= 1.0:
         assert c.shades > 0               # the scene is hit (a 1e-9 scene lies inside the EPSILON of every ray)
+
+
+def test_long_paths_and_parked_hits(oracle):
+    """Hits wait in memory (18 dwords of path state, the bounce count in 26 bits) until 48 lanes can shade together: paths
+    of up to 300 bounces inside a dense triangle soup, few samples (most S blocks are sparse), ragged frame."""
+    import raytracing_c_amd as rt
+    from tests import _oracle
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    hs = make_scene(41, 3000)
+    hs.set_camera(_look_at((0.05, 0.02, 0.1), (0.4, 0.3, -1.0)), 1.3)          # inside the soup
+    for w, h, s, b in ((45, 37, 5, 300), (64, 40, 40, 24)):
+        want = _oracle.render(hs, w, h, s, b, seed=77)
+        got = rt.render_frame(hs, w, h, s, b, seed=77, want_accum=True)
+        assert np.array_equal(want["accum"], got["accum"]), (w, h, s, b)
+        c = got["counters"]
+        for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+            assert want["counters"][k] == getattr(c, k), (k, b)
+        assert c.rays > 3 * c.paths                                            # the paths really are long
