@@ -391,6 +391,19 @@ def main():
     accums = [accum, torch.zeros_like(accum)] if multi else [accum]
     tile_bufs = [tiles, torch.zeros_like(tiles)] if multi else [tiles]
     post_stream = torch.cuda.Stream(device=dev) if multi else None
+    # ... and the path kernels of consecutive frames run on two streams with a device scene each (launch state -- work
+    # counters, schedule feedback, parked hits -- belongs to the device scene): a launch ends ~0.7 ms after its last unit
+    # is handed out, while the bounce chains of its last paths finish; that is 2 % of a whole frame but 13 % of a rank's
+    # launch at 8 GPUs, and the next frame's workgroups take the CUs as they fall idle.  RT_BENCH_OVERLAP=0: one stream.
+    overlap = multi and os.environ.get("RT_BENCH_OVERLAP", "1") != "0"
+    dscenes = [dscene]
+    render_streams = [None, None]
+    if overlap:
+        second = rt.lib.rt_scene_upload(C.byref(hs.scene))
+        if not second:
+            raise RuntimeError("rt_scene_upload: " + rt.last_error())
+        dscenes.append(second)
+        render_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     ev_rendered = [torch.cuda.Event() for _ in range(2)]
     ev_posted = [torch.cuda.Event() for _ in range(2)]
 
@@ -415,14 +428,18 @@ def main():
                 ev_copied[buf].record()
             return
         acc, tl = accums[buf], tile_bufs[buf]
-        if frame_no[0] > 2:
-            cur.wait_event(ev_posted[buf])          # frame k - 2 has left these buffers
-        acc.zero_()
-        if rt.lib.rt_render_accumulate(dscene, C.byref(params), acc.data_ptr(), stream) != 0:
-            raise RuntimeError(rt.last_error())
-        if rt.lib.rt_resolve(C.byref(params), acc.data_ptr(), tl.data_ptr(), None, None, stream) != 0:
-            raise RuntimeError(rt.last_error())
-        ev_rendered[buf].record(cur)
+        rs = render_streams[buf] if overlap else cur
+        with torch.cuda.stream(rs):
+            if frame_no[0] > 2:
+                rs.wait_event(ev_posted[buf])       # frame k - 2 has left these buffers
+            elif overlap:
+                rs.wait_stream(cur)                 # (the first use of the stream: after everything enqueued so far)
+            acc.zero_()
+            if rt.lib.rt_render_accumulate(dscenes[buf if overlap else 0], C.byref(params), acc.data_ptr(), rs.cuda_stream) != 0:
+                raise RuntimeError(rt.last_error())
+            if rt.lib.rt_resolve(C.byref(params), acc.data_ptr(), tl.data_ptr(), None, None, rs.cuda_stream) != 0:
+                raise RuntimeError(rt.last_error())
+            ev_rendered[buf].record(rs)
         post_stream.wait_event(ev_rendered[buf])
         with torch.cuda.stream(post_stream):
             # framebuffer tiles of every rank -> rank 0 (ONE gather: grouped send / recv over xGMI, every peer on its
@@ -501,6 +518,7 @@ def main():
                                              "build_ms": hs.scene_init_seconds * 1e3}},
                        "partition": f"32x32 chunks dealt to {world} GPU(s) by the (cx + B cy) mod world lattice, "
                                     f"{'RCCL' if backend == 'nccl' else backend} gather of u8 tiles to rank 0"
+                                    + ("; consecutive frames' path kernels on two streams" if overlap else "")
                                     if world > 1 else "single GPU"},
             "fps": 1.0 / sec_per_step,
             "msample_per_s": w * h * s / sec_per_step / 1e6,
@@ -523,7 +541,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    rt.lib.rt_scene_release(dscene)
+    for dsc in dscenes:
+        rt.lib.rt_scene_release(dsc)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
