@@ -861,10 +861,12 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   }
 
   if (variant == 5) {
-    // unit = 2 neighbouring pixels x `slab` samples, default 32 (64 paths, pixel-major: the 64 lanes sit on two pixels);
-    // it is also the granularity at which waves share a tile at the end of a launch
+    // unit = 2 neighbouring pixels x `slab` samples, default 64 (128 paths, pixel-major: the 64 lanes of a wave sit on one
+    // pixel, then on its neighbour); it is also the granularity at which waves share a tile at the end of a launch.
+    // Measured on the current kernel, helmet frame / rank 0 of 8: 32 samples 36.9 / 5.39 ms, 64 36.15 / 5.31, 128 36.6
+    // (32 was the optimum before node blocks were culled by the tile's pyramid and hits were parked).
     const int n_samples = K.sample_end - K.sample_first;
-    int cs = p->slab > 0 ? p->slab : 32;
+    int cs = p->slab > 0 ? p->slab : 64;
     int cshift = 0;
     while ((1 << cshift) < cs && (1 << cshift) < n_samples) cshift++;
     K.chunk_shift = cshift;

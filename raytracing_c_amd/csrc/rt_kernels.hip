@@ -1242,8 +1242,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // what changes is where the work comes from and how the loop is cut:
 //
 //  * A wave OWNS an 8x8-pixel tile (taken from the head counter, expensive tiles first) and pulls UNITS of it --
-//    2 neighbouring pixels x 2^chunk_shift samples (64 paths at 32 samples: one wave-load, pixel-major, so the 64 lanes
-//    sit on two pixels: coherent nodes, leaves and texels), one or two per atomic -- from the tile's own counter
+//    2 neighbouring pixels x 2^chunk_shift samples (128 paths at 64 samples, pixel-major, so the 64 lanes
+//    sit on one or two pixels: coherent nodes, leaves and texels), one or two per atomic -- from the tile's own counter
 //    `tile_next[tile]` until the tile is exhausted.  Lanes whose path ended are refilled across unit boundaries, so
 //    there is no end-of-item drain (the scheduled kernel drains the wave at the end of every item, 40 us to 0.4 ms each);
 //    the wave drains once per TILE.
@@ -1593,7 +1593,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     HitRec hit;
     hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
 
-    // The tile hands out UNITS (2 pixels x one block of samples = 64 paths at 32 samples: one wave-load, lanes on two
+    // The tile hands out UNITS (2 pixels x one block of samples = 128 paths at 64 samples, lanes on one or two
     // pixels).  A wave grabs `grab_max` consecutive units per atomic while the tile has plenty left, fewer towards its
     // end: what a wave still holds when the launch runs dry is its tail.  Current unit (wave-uniform): paths
     // [c_next, c_end) at pixels (c_x0 .. c_x0 + 1, c_y), samples from c_s0.

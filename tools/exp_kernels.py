@@ -32,7 +32,7 @@ def main():
     ranks = [int(r) for r in os.environ.get("RT_EXP_RANKS", "0,3,5").split(",") if r != ""]
 
     def run(rank, world, n):
-        p = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, rank, world, 0, 0)
+        p = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, rank, world, int(os.environ.get("RT_EXP_SLAB", "0")), 0)
         for i in range(n + 2):
             if i == 2:
                 rt.lib.rt_kernel_timing_reset()
