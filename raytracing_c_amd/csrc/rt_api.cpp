@@ -895,10 +895,11 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     int64_t chunks = (int64_t)K.n_tiles * K.n_chunks_tile;
     n_waves = g_num_cus * waves_per_cu;
     if ((int64_t)n_waves > chunks) n_waves = (int)chunks;
-    // units per atomic: 2 (measured, helmet frame: 4 -> 47.27 ms, 2 -> 47.19, 1 -> 47.45); 1 when the launch has few tiles
-    // per wave (a rank of the 8-GPU partition: 4 -> 6.97 / 7.14 / 6.79 ms, 2 -> 6.72 / 6.77 / 6.46, 1 -> 6.65 / 6.66 / 6.45):
-    // what a wave still holds when the launch runs dry is its tail
-    K.grab_max = (int64_t)K.n_tiles < (int64_t)2 * n_waves ? 1 : 2;
+    // units per atomic: 1 unit of 128 paths (what a wave still holds when the launch runs dry is its tail).  Measured with
+    // units of 64 paths: helmet frame 4 -> 47.27 ms, 2 -> 47.19, 1 -> 47.45; a rank of the 8-GPU partition 4 -> 6.97 / 7.14
+    // / 6.79 ms, 2 -> 6.72 / 6.77 / 6.46, 1 -> 6.65 / 6.66 / 6.45.  With units of 128 paths: frame 1 -> 36.25, 2 -> 36.4,
+    // 4 -> 37.2; ranks 0 / 4 of 8: 5.33 / 5.63, 5.34 / 5.61, 5.86 / 6.48.  Smaller units (few samples) are taken in pairs.
+    K.grab_max = (cshift >= 6 || (int64_t)K.n_tiles < (int64_t)2 * n_waves) ? 1 : 2;
     K.pyr_nodes = K.n_lds_nodes;
     if (const char *e = getenv("RT_PYRAMID")) {
       if (atoi(e) == 0) K.pyr_nodes = 0;
