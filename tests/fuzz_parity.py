@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""GPU fuzz (one-off assurance, not part of the test suite): random triangle soups, random cameras (far, near, inside, looking
+"""GPU fuzz (one-off assurance; a script, not collected by pytest): random triangle soups, random cameras (far, near, inside, looking
 away), random frame shapes / sample counts / bounce limits / builders / scene scales; the HIP path through the C-ABI must give
-the oracle's radiance sums and counters bit for bit.    python tools/fuzz_parity.py [seconds] [first seed]"""
+the oracle's radiance sums and counters bit for bit.    python tests/fuzz_parity.py [seconds] [first seed]   (RT_FUZZ_LARGE=1: frames of 200 ... 900 pixels)"""
 import os
 import sys
 import time
