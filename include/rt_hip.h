@@ -171,6 +171,9 @@ extern int rt_test_rcp_sweep(u64 out[4]);
 /* the kernels' sRGB decode of a texture sample against rt_srgb_to_linear1() for every float in [0, 2] (and 4 M negative ones):
  * out[0] patterns compared, out[1] differing (0 expected), out[2] first differing pattern + 1 */
 extern int rt_test_srgb_sweep(u64 out[3]);
+/* the tile-stream kernel's fixed-point conversion of a sample against rt_accum_quantize() over all 2^32 bit patterns:
+ * out[0] differing patterns (0 expected), out[1] first differing pattern + 1 */
+extern int rt_test_quantize_sweep(u64 out[2]);
 
 /* Closest hit of n rays (host arrays, 6 f32 per ray: origin, direction) against
  * an uploaded scene: out_t[n], out_tri[n] (-1 = miss), out_uv[2n]. */

@@ -29,6 +29,7 @@ int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, const in
 int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream);
 int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_srgb_sweep(unsigned long long *counts, hipStream_t stream);
+int rt_launch_test_quantize_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
                          hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
@@ -1349,6 +1350,21 @@ extern "C" int rt_test_srgb_sweep(u64 out[3]) {
   int rc = rt_launch_test_srgb_sweep(b.as<unsigned long long>(), nullptr);
   if (rc == 0) rc = (int)hipMemcpy(out, b.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   if (rc != 0) return rt_fail("rt_test_srgb_sweep failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+// The tile-stream kernel's shift-based fixed-point conversion of a sample against rt_accum_quantize() over all 2^32 bit
+// patterns: out[0] differing patterns (0 expected), out[1] first differing pattern + 1.
+extern "C" int rt_test_quantize_sweep(u64 out[2]) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (ensure_device() != 0) return -1;
+  if (!out) return rt_fail("rt_test_quantize_sweep: NULL");
+  DevBuf b;
+  HIP_TRY(b.alloc(2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(b.p, 0, 2 * sizeof(unsigned long long)));
+  int rc = rt_launch_test_quantize_sweep(b.as<unsigned long long>(), nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out, b.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (rc != 0) return rt_fail("rt_test_quantize_sweep failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 

@@ -215,6 +215,19 @@ __device__ __forceinline__ bool rcp_exact_outside(float x) {
 // is infinite / NaN, inside the domain on which rcp_exact() equals the division -- same bits, 5 instructions fewer.
 __device__ __forceinline__ rt_v3 normalize_dev(rt_v3 v) { return rt_v3_scale(v, rcp_exact(rt_sqrtf(rt_v3_dot(v, v)))); }
 
+// rt_accum_quantize() (rt_math.h: clamp to [0, 2^20], times 2^32 in double, truncate to u64) by shifts of the mantissa:
+// mantissa << 29 is the value at exponent field 147 (2^20), one right shift brings it to its own exponent.  Same integer
+// for every float (rt_test_quantize_sweep: all 2^32 bit patterns); the f64 conversions and multiplies cost twice as much.
+__device__ __forceinline__ unsigned long long accum_quantize_dev(float c) {
+  float v = (c > 0.0f) ? c : 0.0f;
+  v = (v > RT_ACCUM_MAX) ? RT_ACCUM_MAX : v;
+  const uint32_t b = __float_as_uint(v);
+  const uint32_t e = b >> 23;                                          // 0 .. 147 after the clamp
+  const unsigned long long m = (unsigned long long)((b & 0x007FFFFFu) | 0x00800000u) << 29;
+  const uint32_t k = 147u - e;
+  return m >> (k < 63u ? k : 63u);                                     // (exponent field 0: zero and denormals end as 0)
+}
+
 // 8-triangle test of leaf group g (raytracer.c:84-188 + min_f32x8 :15-32).
 // One triangle: Moeller-Trumbore without determinant test; returns the sanitised distance.
 __device__ __forceinline__ float tri_test(const Ray3 &r, float ax, float ay, float az, float e1x, float e1y, float e1z,
@@ -1641,9 +1654,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             if (back > 0) {
               if (done) {                                               // (an environment lane is idle once its sample is added)
                 unsigned long long *ap = reinterpret_cast<unsigned long long *>(lds_at(smem, acc_off) + pix * 6);
-                atomicAdd(ap + 0, (unsigned long long)rt_accum_quantize(radiance.x));
-                atomicAdd(ap + 1, (unsigned long long)rt_accum_quantize(radiance.y));
-                atomicAdd(ap + 2, (unsigned long long)rt_accum_quantize(radiance.z));
+                atomicAdd(ap + 0, accum_quantize_dev(radiance.x));
+                atomicAdd(ap + 1, accum_quantize_dev(radiance.y));
+                atomicAdd(ap + 2, accum_quantize_dev(radiance.z));
                 phase = PH_NEED;
                 done = false;
               }
@@ -1690,9 +1703,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           // (32-bit address arithmetic from the wave's byte offset: `acc + pix * 3` is a 64-bit multiply-add on a pointer
           // that is kept in scratch)
           unsigned long long *ap = reinterpret_cast<unsigned long long *>(lds_at(smem, acc_off) + pix * 6);
-          atomicAdd(ap + 0, (unsigned long long)rt_accum_quantize(radiance.x));
-          atomicAdd(ap + 1, (unsigned long long)rt_accum_quantize(radiance.y));
-          atomicAdd(ap + 2, (unsigned long long)rt_accum_quantize(radiance.z));
+          atomicAdd(ap + 0, accum_quantize_dev(radiance.x));
+          atomicAdd(ap + 1, accum_quantize_dev(radiance.y));
+          atomicAdd(ap + 2, accum_quantize_dev(radiance.z));
           phase = PH_NEED;
         }
         w_shades += (uint32_t)__popcll(__ballot(cn.shades != 0));
@@ -2267,6 +2280,20 @@ __global__ void rt_test_rcp_sweep_kernel(unsigned long long *counts) {
   if (first) atomicMax(&counts[3], (unsigned long long)first);
 }
 
+// accum_quantize_dev(x) against rt_accum_quantize(x) for all 2^32 bit patterns: counts[0] = patterns that differ,
+// counts[1] = first differing pattern + 1.
+__global__ void rt_test_quantize_sweep_kernel(unsigned long long *counts) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t bad = 0, first = 0;
+  for (uint32_t k = 0; k < 256u; k++) {
+    const uint32_t b = tid * 256u + k;
+    const float x = __uint_as_float(b);
+    if (accum_quantize_dev(x) != (unsigned long long)rt_accum_quantize(x)) { bad += 1; if (!first) first = b + 1u; }
+  }
+  if (bad) atomicAdd(&counts[0], (unsigned long long)bad);
+  if (first) atomicMax(&counts[1], (unsigned long long)first);
+}
+
 // srgb_to_linear_tex1(x) against rt_srgb_to_linear1(x) for every float in [0, 2] and in [-0.046875, -0.03125]: counts[0] =
 // patterns compared (2^30 + 2^22), counts[1] = patterns that differ, counts[2] = first differing pattern + 1.
 __global__ void rt_test_srgb_sweep_kernel(unsigned long long *counts) {
@@ -2422,6 +2449,11 @@ extern "C" int rt_launch_test_math(int op, int n, const float *x, const float *y
 
 extern "C" int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream) {
   hipLaunchKernelGGL(rt_test_rcp_sweep_kernel, dim3(65536), dim3(256), 0, stream, counts);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rt_launch_test_quantize_sweep(unsigned long long *counts, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_test_quantize_sweep_kernel, dim3(65536), dim3(256), 0, stream, counts);
   return (int)hipGetLastError();
 }
 

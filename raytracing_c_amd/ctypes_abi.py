@@ -151,5 +151,5 @@ EXPORTED_SYMBOLS = [
     "rt_scene_upload", "rt_scene_release", "rt_scene_invalidate", "rt_scene_device_bytes", "rt_set_camera",
     "rt_chunk_count", "rt_chunk_owner", "rt_local_chunk_count", "rt_max_local_chunk_count", "rt_local_chunk_list", "rt_render_accumulate", "rt_resolve", "rt_untile",
     "rt_denoise", "rt_render_frame", "rt_get_counters", "rt_get_sched_stats", "rt_get_wave_times", "rt_last_kernel_ms", "rt_kernel_timing_reset", "rt_kernel_timing_mean_ms",
-    "rt_test_math", "rt_test_rcp_sweep", "rt_test_srgb_sweep", "rt_test_trace", "rt_test_texture",
+    "rt_test_math", "rt_test_rcp_sweep", "rt_test_srgb_sweep", "rt_test_quantize_sweep", "rt_test_trace", "rt_test_texture",
 ]

@@ -122,6 +122,7 @@ def _declare(d):
     d.rt_test_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
     d.rt_test_rcp_sweep.argtypes = [vp]
     d.rt_test_srgb_sweep.argtypes = [vp]
+    d.rt_test_quantize_sweep.argtypes = [vp]
     d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     d.render_thread_proc.argtypes = [P(abi.Rendering_Context)]

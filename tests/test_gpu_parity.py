@@ -89,6 +89,15 @@ def test_short_reciprocal_equals_the_division(rt, oracle):
     assert inside.sum() > 300000 and (~inside).sum() > 1000
 
 
+def test_shift_quantisation_equals_the_double_one(rt):
+    """The tile-stream kernel turns a sample into 32.32 fixed point by shifting the float's mantissa instead of going through
+    double (rt_accum_quantize, rt_math.h): the same integer for every one of the 2^32 bit patterns, NaN and negatives (0),
+    infinity and anything above 2^20 (clamped) included."""
+    out = (C.c_uint64 * 2)()
+    assert rt.lib.rt_test_quantize_sweep(out) == 0, rt.last_error()
+    assert int(out[0]) == 0, f"first differing pattern {int(out[1]) - 1:#010x}"
+
+
 def test_texture_srgb_decode_equals_the_division(rt, oracle):
     """The kernels decode a texture sample with (x + 0.055f) * RN(1 / 1.055f) corrected by the exact residual instead of the
     division by 1.055f of common.h:84-91.  Every float in [0, 2] and in [-0.046875, -0.03125] -- a sample lies in [0, 0.9961] --
