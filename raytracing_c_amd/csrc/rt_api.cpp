@@ -172,6 +172,7 @@ struct RT_Device_Scene {
   int32_t      n_triangles = 0, n_materials = 0, n_textures = 0;
   int64_t      bytes = 0;
   float        max_edge = 0.0f;   // largest |component| of an edge b - a, c - a in the leaf tiles (NaN if one is NaN)
+  bool         boxes_ordered = true;      // every child box of every node has min <= max on every axis (no NaN either)
   // fingerprint of the host scene this was built from (scene_fingerprint)
   uint64_t     fp = 0;
   // launch state of this device scene: two device scenes can have launches in flight on two streams at once
@@ -491,9 +492,15 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   }
 
   std::vector<float> nodes;
+  bool boxes_ordered = true;
   if (scene->bvh.depth > 0) {
     const float *src = (const float *)scene->bvh.nodes.data;
     nodes.assign(src, src + (size_t)scene->bvh.nodes.len * 48);
+    // the LDS node blocks pick the near / far plane of a slab by the sign of the ray direction: valid for min <= max
+    // (what scene_init builds; a Scene from elsewhere is checked, and traverses through the min / max form otherwise)
+    for (size_t nd = 0; nd < (size_t)scene->bvh.nodes.len && boxes_ordered; nd++)
+      for (int k = 0; k < 24; k++)
+        if (!(nodes[nd * 48 + k] <= nodes[nd * 48 + 24 + k])) { boxes_ordered = false; break; }
   }
 
   int bg = texture_index((Image const *)scene->background.data, pool);
@@ -518,6 +525,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   d->n_nodes = (int32_t)scene->bvh.nodes.len;
   d->n_triangles = n;
   d->max_edge = max_edge;
+  d->boxes_ordered = boxes_ordered;
   d->n_materials = (int32_t)(mats.size() / 20);
   d->n_textures = (int32_t)pool.descs.size();
   d->fp = scene_fingerprint(scene);
@@ -815,6 +823,7 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     int room = (lds_limit - waves_per_block * per_wave) / 208;
     if (room < 0) room = 0;
     K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
+    if (variant == 5 && !d->boxes_ordered) K.n_lds_nodes = 0;      // (the tile-stream kernel's LDS node blocks assume min <= max)
     if (const char *e = getenv("RT_LDS_NODES")) {
       int v = atoi(e);
       if (v >= 0 && v < K.n_lds_nodes) K.n_lds_nodes = v;

@@ -139,6 +139,7 @@ __device__ __forceinline__ float slab_entry_child(const float *n, const Ray3 &r)
 #define NODE_GLOBAL 0     // per-lane vector loads from HBM/L2/L1
 #define NODE_SCALAR 1     // wave-uniform node: s_load through the scalar cache
 #define NODE_LDS    2     // per-lane reads from the workgroup's LDS copy of the top of the tree
+#define NODE_LDS_ORDERED 3   // NODE_LDS with the slab planes picked by address (FAST rays, boxes with min <= max)
 #define RT_LDS_NODE_F4 13 // LDS node stride in float4 (12 data + 1 pad: 13 is odd, so random nodes spread over all 16-byte slots of a bank row)
 
 // float4 index of LDS node `node`: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter
@@ -154,8 +155,33 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
     for (int k = 0; k < 8; k++) {
       d[k] = as_i(slab_entry<FAST>(r, nb[k], nb[8 + k], nb[16 + k], nb[24 + k], nb[32 + k], nb[40 + k], hit_t));
     }
+  } else if (FAST && MODE == NODE_LDS_ORDERED) {
+    // Near and far plane of every slab picked by ADDRESS from the sign of the reciprocal direction instead of by min / max
+    // of the two products: with min <= max in every box (checked at upload, rt_api.cpp) and NaN-free operands,
+    // (mn - o) * inv <= (mx - o) * inv for inv > 0 and >= for inv < 0 -- rounding is monotonic -- so the picked product IS
+    // the minimum (maximum); for inv = 0 both are zero.  Six min / max fewer per child.
+    const char *nbase = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node));
+    const int nx = (as_i(r.inv_x) >> 31) & 96, ny = (as_i(r.inv_y) >> 31) & 96, nz = (as_i(r.inv_z) >> 31) & 96;   // bytes: min rows 0 / 32 / 64, max rows +96
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float4 ax = *reinterpret_cast<const float4 *>(nbase + nx + h * 16), bx = *reinterpret_cast<const float4 *>(nbase + (96 - nx) + h * 16);
+      const float4 ay = *reinterpret_cast<const float4 *>(nbase + 32 + ny + h * 16), by = *reinterpret_cast<const float4 *>(nbase + 32 + (96 - ny) + h * 16);
+      const float4 az = *reinterpret_cast<const float4 *>(nbase + 64 + nz + h * 16), bz = *reinterpret_cast<const float4 *>(nbase + 64 + (96 - nz) + h * 16);
+      const float nxs[4] = {ax.x, ax.y, ax.z, ax.w}, fxs[4] = {bx.x, bx.y, bx.z, bx.w};
+      const float nys[4] = {ay.x, ay.y, ay.z, ay.w}, fys[4] = {by.x, by.y, by.z, by.w};
+      const float nzs[4] = {az.x, az.y, az.z, az.w}, fzs[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float sx = (nxs[k] - r.o.x) * r.inv_x, bxx = (fxs[k] - r.o.x) * r.inv_x;
+        const float sy = (nys[k] - r.o.y) * r.inv_y, byy = (fys[k] - r.o.y) * r.inv_y;
+        const float sz = (nzs[k] - r.o.z) * r.inv_z, bzz = (fzs[k] - r.o.z) * r.inv_z;
+        const float t_minv = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+        const float t_maxv = fmin_hw(hit_t, fmin_hw(bxx, fmin_hw(byy, bzz)));
+        d[h * 4 + k] = as_i((t_minv < t_maxv) ? t_minv : RT_INF);
+      }
+    }
   } else {
-    const float4 *nb = (MODE == NODE_LDS) ? (lds_nodes + lds_node_f4(node))
+    const float4 *nb = (MODE == NODE_LDS || MODE == NODE_LDS_ORDERED) ? (lds_nodes + lds_node_f4(node))
                                           : (reinterpret_cast<const float4 *>(P.nodes) + (size_t)node * 12);
 #pragma unroll
     for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
@@ -1330,21 +1356,34 @@ __device__ __forceinline__ uint32_t pyramid_cull_mask(const float4 *lds_nodes, c
   return (m | (m >> 8) | (m >> 16) | (m >> 24)) & 0xFFu;
 }
 
+// slab_entry<true>() of child k of an LDS node with the planes picked by address (see NODE_LDS_ORDERED)
+__device__ __forceinline__ float slab_entry_ordered(const Ray3 &r, const char *nbase, int k, int nx, int ny, int nz, float t_max) {
+  const char *b = nbase + k * 4;
+  const float sx = (*reinterpret_cast<const float *>(b + nx) - r.o.x) * r.inv_x;
+  const float bx = (*reinterpret_cast<const float *>(b + (96 - nx)) - r.o.x) * r.inv_x;
+  const float sy = (*reinterpret_cast<const float *>(b + 32 + ny) - r.o.y) * r.inv_y;
+  const float by = (*reinterpret_cast<const float *>(b + 32 + (96 - ny)) - r.o.y) * r.inv_y;
+  const float sz = (*reinterpret_cast<const float *>(b + 64 + nz) - r.o.z) * r.inv_z;
+  const float bz = (*reinterpret_cast<const float *>(b + 64 + (96 - nz)) - r.o.z) * r.inv_z;
+  const float t_minv = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+  const float t_maxv = fmin_hw(t_max, fmin_hw(bx, fmin_hw(by, bz)));
+  return (t_minv < t_maxv) ? t_minv : RT_INF;
+}
+
 // node_enter() for a node of which only the children in `surv` (1 to 4 of them, wave-uniform) can be entered: the
 // same word -- the other children are misses, which rank behind every candidate and are never read.
 __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *lds_nodes, int node, uint32_t surv,
                                                    float hit_t) {
-  const float *nf = reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node));
+  const char *nbase = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node));
+  const int nx = (as_i(r.inv_x) >> 31) & 96, ny = (as_i(r.inv_y) >> 31) & 96, nz = (as_i(r.inv_z) >> 31) & 96;
   const int n = (int)__popc(surv);
   const int k0 = (int)__builtin_ctz(surv);
-  const float *b0 = nf + k0;
-  const int e0 = as_i(slab_entry<true>(r, b0[0], b0[8], b0[16], b0[24], b0[32], b0[40], hit_t));
+  const int e0 = as_i(slab_entry_ordered(r, nbase, k0, nx, ny, nz, hit_t));
   const uint32_t f0 = 1u - (((uint32_t)e0 + 0x00800000u) >> 31);                   // 1 iff e0 is finite (a candidate)
   if (n == 1) return (uint32_t)k0 | (f0 << 24);
   surv &= surv - 1u;
   const int k1 = (int)__builtin_ctz(surv);
-  const float *b1 = nf + k1;
-  const int e1 = as_i(slab_entry<true>(r, b1[0], b1[8], b1[16], b1[24], b1[32], b1[40], hit_t));
+  const int e1 = as_i(slab_entry_ordered(r, nbase, k1, nx, ny, nz, hit_t));
   const uint32_t f1 = 1u - (((uint32_t)e1 + 0x00800000u) >> 31);
   if (n == 2) {
     const bool swap = e1 < e0;                                                     // ties: lowest index first
@@ -1353,16 +1392,14 @@ __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *
   }
   surv &= surv - 1u;
   const int k2 = (int)__builtin_ctz(surv);
-  const float *b2 = nf + k2;
-  const int e2 = as_i(slab_entry<true>(r, b2[0], b2[8], b2[16], b2[24], b2[32], b2[40], hit_t));
+  const int e2 = as_i(slab_entry_ordered(r, nbase, k2, nx, ny, nz, hit_t));
   const uint32_t f2 = 1u - (((uint32_t)e2 + 0x00800000u) >> 31);
   int e3 = 0x7F800000, k3 = 0;
   uint32_t f3 = 0;
   if (n == 4) {
     surv &= surv - 1u;
     k3 = (int)__builtin_ctz(surv);
-    const float *b3 = nf + k3;
-    e3 = as_i(slab_entry<true>(r, b3[0], b3[8], b3[16], b3[24], b3[32], b3[40], hit_t));
+      e3 = as_i(slab_entry_ordered(r, nbase, k3, nx, ny, nz, hit_t));
     f3 = 1u - (((uint32_t)e3 + 0x00800000u) >> 31);
   }
   const int e[4] = {e0, e1, e2, e3};
@@ -1896,7 +1933,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             if (surv <= 0xFFu) {
               cur = surv ? node_enter_few(ray, lds_nodes, node, surv, hit.t) : 0u;
             } else if (all_fast) {
-              if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes);
+              if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
               else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
             } else {
               cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);

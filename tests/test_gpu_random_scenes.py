@@ -207,3 +207,28 @@ def test_long_paths_and_parked_hits(oracle):
         for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
             assert want["counters"][k] == getattr(c, k), (k, b)
         assert c.rays > 3 * c.paths                                            # the paths really are long
+
+
+def test_inverted_boxes_take_the_min_max_path(oracle):
+    """The LDS node blocks of the tile-stream kernel pick a slab's near / far plane by the sign of the ray direction, which
+    presumes min <= max in every child box (what scene_init builds).  A Scene from elsewhere may not keep that: the upload
+    checks, and such a scene is traversed through the min / max form of raytracer.c:209-228 -- same image as the oracle,
+    which always uses that form."""
+    import raytracing_c_amd as rt
+    from tests import _oracle
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    hs = make_scene(51, 900)
+    nodes = hs.nodes_array()                        # (n, 6, 8) view of the host scene: rows min x y z, max x y z
+    swapped = 0
+    for nd in (0, 1, 5, 9):
+        for k in range(8):
+            if nodes[nd, 0, k] < nodes[nd, 3, k] and swapped < 6:
+                nodes[nd, 0, k], nodes[nd, 3, k] = nodes[nd, 3, k].copy(), nodes[nd, 0, k].copy()     # min.x <-> max.x
+                swapped += 1
+    assert swapped == 6
+    want = _oracle.render(hs, 96, 64, 24, 6, seed=5)
+    got = rt.render_frame(hs, 96, 64, 24, 6, seed=5, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    c = got["counters"]
+    for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
+        assert want["counters"][k] == getattr(c, k), k
