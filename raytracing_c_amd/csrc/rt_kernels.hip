@@ -1973,8 +1973,18 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
               bool go = true;
               if ((dirty >> level) & 1u) {
                 float dj;
-                if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
-                else dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
+                if (LDSN && node < n_lds) {
+                  // entry distance from the three NEAR planes, picked by address (see NODE_LDS_ORDERED); the rays that are
+                  // not NaN-free -- a lane in a blue moon -- redo it through the min / max form
+                  const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
+                  const float sx = (*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)) - ray.o.x) * ray.inv_x;
+                  const float sy = (*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)) - ray.o.y) * ray.inv_y;
+                  const float sz = (*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)) - ray.o.z) * ray.inv_z;
+                  dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+                  if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
+                } else {
+                  dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
+                }
                 if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
               }
               if (go) {
