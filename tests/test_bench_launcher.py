@@ -37,3 +37,21 @@ def test_bench_launcher_relays_failure_status():
     r = _run("--gpus", "2", "--dry-run", "--config-does-not-exist")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_distributed_pipeline_on_one_gpu(tmp_path):
+    """The N > 1 frame pipeline of bench.py -- path kernels of consecutive frames on two streams with a device scene each,
+    RCCL gather of the tiles on a third, untile, D2H -- rehearsed with ONE rank (RT_BENCH_FORCE_DIST=1): the frame it
+    delivers is the frame of the plain single-GPU path, byte for byte, with and without the overlap."""
+    common = ("--steps", "3", "--warmup", "2", "--samples", "24", "--no-cpu-baseline", "--no-bvh-compare")
+    imgs = []
+    for name, env in (("plain", {}), ("dist", {"RT_BENCH_FORCE_DIST": "1"}),
+                      ("dist_one_stream", {"RT_BENCH_FORCE_DIST": "1", "RT_BENCH_OVERLAP": "0"})):
+        png = str(tmp_path / f"{name}.png")
+        r = _run(*common, "--save", png, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 1 and out["value"] > 0
+        imgs.append(open(png, "rb").read())
+    assert imgs[0] == imgs[1] == imgs[2]
