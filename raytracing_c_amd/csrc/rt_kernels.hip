@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                 // exactly one wave receives the tile's last unit: it closes the tile in the group summary
                 if (u_end == n_chunks_tile && lane == 0) atomicSub(&A->open_groups[tile_idx >> 6], 1u);
                 if (t_wave_start) t_last_grab = __builtin_amdgcn_s_memrealtime();
-                // next grab: `grab_max` units (4 = one tile row) while the tile has plenty left, fewer towards its end.
+                // next grab: `grab_max` units while the tile has plenty left, fewer towards its end.
                 // (A launch-wide count of the remaining units would be the better guide, but a counter that every grab
                 // updates -- one address or 64 shards of one line -- made the frame 2x slower: measured, removed.)
                 const uint32_t left = n_chunks_tile - u_end;
