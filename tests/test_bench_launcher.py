@@ -55,3 +55,21 @@ def test_bench_distributed_pipeline_on_one_gpu(tmp_path):
         assert out["n_gpus"] == 1 and out["value"] > 0
         imgs.append(open(png, "rb").read())
     assert imgs[0] == imgs[1] == imgs[2]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_deliver_the_same_frame(tmp_path):
+    """`python bench.py --gpus 2` (the driver's form: the parent starts the ranks) with both ranks on GPU 0 and the tiles
+    exchanged over gloo -- what a one-GPU box can run of the N > 1 path: lattice partition, two frames in flight, gather
+    to rank 0, untile.  Rank 0's frame equals the single-GPU frame byte for byte."""
+    common = ("--steps", "3", "--warmup", "1", "--samples", "24", "--no-cpu-baseline", "--no-bvh-compare")
+    one, two = str(tmp_path / "one.png"), str(tmp_path / "two.png")
+    r = _run(*common, "--save", one)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _run("--gpus", "2", *common, "--save", two, env={"RT_BENCH_BACKEND": "gloo", "RT_BENCH_DEVICE": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "two streams" in out["config"]["partition"]
+    assert open(one, "rb").read() == open(two, "rb").read()
