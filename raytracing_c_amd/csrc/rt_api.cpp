@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -39,6 +40,10 @@ int rt_launch_stream_init(int n_tiles, uint32_t *tile_next, uint32_t *open_group
 int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
+// rt_wavefront.hip
+int rt_wf_launch_camera(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream);
+int rt_wf_launch_trace(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream);
+int rt_wf_launch_shade(const RT_KParams *P, int n_blocks, int first, hipStream_t stream);
 }
 
 // ---------------------------------------------------------------------------------
@@ -182,6 +187,13 @@ struct RT_Device_Scene {
   int32_t             tile_next_n = 0;
   uint32_t           *park = nullptr;          // tile-stream kernel: parked hits, [waves][18][128]
   int32_t             park_waves = 0;
+  // wavefront pipeline (rt_wavefront.hip): record queues between the camera / shade / trace kernels
+  uint32_t           *wf_hit0 = nullptr, *wf_hit = nullptr, *wf_ray[2] = {nullptr, nullptr};
+  uint32_t           *wf_cnt = nullptr;        // records per chunk: hit0 | hit | ray[0] | ray[1]
+  uint32_t           *wf_ctl = nullptr;        // WF_N_CTL control words, one per 64-byte line
+  uint32_t           *wf_ctl_host = nullptr;   // pinned copy the host reads after a pass
+  int64_t             wf_soft0 = 0, wf_hard0 = 0, wf_ray_chunks = 0, wf_hit_chunks = 0;   // capacities in chunks
+  int32_t             wf_waves = 0;            // waves the capacities were sized for
   // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
   uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
   uint32_t    *order = nullptr, *hist = nullptr;
@@ -205,6 +217,13 @@ static void free_device_scene(RT_Device_Scene *d) {
   (void)hipFree(d->work_head);
   (void)hipFree(d->tile_next);
   (void)hipFree(d->park);
+  (void)hipFree(d->wf_hit0);
+  (void)hipFree(d->wf_hit);
+  (void)hipFree(d->wf_ray[0]);
+  (void)hipFree(d->wf_ray[1]);
+  (void)hipFree(d->wf_cnt);
+  (void)hipFree(d->wf_ctl);
+  if (d->wf_ctl_host) (void)hipHostFree(d->wf_ctl_host);
   (void)hipFree(d->cost[0]);
   (void)hipFree(d->cost[1]);
   (void)hipFree(d->order);
@@ -781,6 +800,117 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   return 0;
 }
 
+
+// ---- wavefront pipeline (rt_wavefront.hip) --------------------------------------------------------------------------
+// Camera kernel -> (shade, trace) per bounce, joined by record queues in HBM.  The queues are sized for `cap` camera-ray
+// hits per pass (grown on demand, never beyond RT_WF_CAP records); a frame with more first hits than that takes several
+// passes: the camera kernel stops taking units when its hit queue is nearly full, the bounces run, and the host -- which
+// reads one control word after every pass -- launches it again; tile_next / work_head keep the position.
+static int64_t g_wf_cap_records = (int64_t)96 << 20;
+
+static int wavefront_ensure_queues(RT_Device_Scene *d, int64_t paths, int cam_waves, int max_waves) {
+  const int64_t want = paths < g_wf_cap_records ? paths : g_wf_cap_records;
+  // chunks: a closed chunk holds at least WF_CHUNK - 63 records; every wave leaves one open chunk behind
+  const int64_t fill = WF_CHUNK - 63;
+  const int64_t soft = (want + fill - 1) / fill + cam_waves + 1;
+  if (d->wf_ctl && d->wf_soft0 >= soft && d->wf_waves >= max_waves) return 0;
+  (void)hipFree(d->wf_hit0); (void)hipFree(d->wf_hit); (void)hipFree(d->wf_ray[0]); (void)hipFree(d->wf_ray[1]);
+  (void)hipFree(d->wf_cnt); (void)hipFree(d->wf_ctl);
+  d->wf_hit0 = d->wf_hit = d->wf_ray[0] = d->wf_ray[1] = d->wf_cnt = d->wf_ctl = nullptr;
+  d->wf_soft0 = 0;
+  const int64_t hard = soft + 2 * (int64_t)cam_waves + 8;                      // a stopped wave closes at most two more chunks
+  const int64_t ray_chunks = (hard * WF_CHUNK + fill - 1) / fill + max_waves + 8;   // rays <= hits
+  const int64_t hit_chunks = (ray_chunks * WF_CHUNK + fill - 1) / fill + max_waves + 8;   // hits <= rays
+  HIP_TRY(hipMalloc(&d->wf_hit0, (size_t)hard * WF_HIT0_FIELDS * WF_CHUNK * 4));
+  HIP_TRY(hipMalloc(&d->wf_hit, (size_t)hit_chunks * WF_HIT_FIELDS * WF_CHUNK * 4));
+  HIP_TRY(hipMalloc(&d->wf_ray[0], (size_t)ray_chunks * WF_RAY_FIELDS * WF_CHUNK * 4));
+  HIP_TRY(hipMalloc(&d->wf_ray[1], (size_t)ray_chunks * WF_RAY_FIELDS * WF_CHUNK * 4));
+  HIP_TRY(hipMalloc(&d->wf_cnt, (size_t)(hard + hit_chunks + 2 * ray_chunks) * 4));
+  HIP_TRY(hipMalloc(&d->wf_ctl, (size_t)WF_N_CTL * WF_CTL_STRIDE * 4));
+  if (!d->wf_ctl_host) HIP_TRY(hipHostMalloc((void **)&d->wf_ctl_host, (size_t)WF_N_CTL * WF_CTL_STRIDE * 4, hipHostMallocDefault));
+  d->wf_soft0 = soft; d->wf_hard0 = hard; d->wf_ray_chunks = ray_chunks; d->wf_hit_chunks = hit_chunks;
+  d->wf_waves = max_waves;
+  return 0;
+}
+
+// K: filled for the tile-stream kernel (units, tile counters, schedule feedback, LDS nodes for 16-wave workgroups)
+static int launch_wavefront(RT_Device_Scene *d, RT_KParams &K, hipStream_t stream) {
+  int geometry = 0;
+  if (const char *e = getenv("RT_WF_GEOMETRY")) { geometry = atoi(e); if (geometry < 0 || geometry > 2) geometry = 0; }
+  int geometry_cam = geometry;
+  if (const char *e = getenv("RT_WF_GEOMETRY_CAM")) { geometry_cam = atoi(e); if (geometry_cam < 0 || geometry_cam > 2) geometry_cam = 0; }
+  if (const char *e = getenv("RT_WF_CAP")) { long long v = atoll(e); if (v >= 1024) g_wf_cap_records = v; }
+  const int lds_limit = 160 * 1024;
+  static const int wpb_of[3] = {16, 12, 10}, bpc_of[3] = {1, 2, 2};
+  const int wpb_cam = wpb_of[geometry_cam], bpc_cam = bpc_of[geometry_cam], wpb_tr = wpb_of[geometry], bpc_tr = bpc_of[geometry];
+  const int per_wave_cam = (K.depth > 0 ? K.depth : 1) * 256 + 1536, per_wave_trace = per_wave_cam;   // perm stack + accumulator tile
+  const int cam_blocks = g_num_cus * bpc_cam, cam_waves = cam_blocks * wpb_cam;
+  const int tr_blocks = g_num_cus * bpc_tr, tr_waves = tr_blocks * wpb_tr;
+  int shade_blocks_per_cu = 5;
+  if (const char *e = getenv("RT_WF_SHADE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 8) shade_blocks_per_cu = v; }
+  const int shade_blocks = g_num_cus * shade_blocks_per_cu, shade_waves = shade_blocks * 4;
+  const int max_waves = std::max(std::max(cam_waves, tr_waves), shade_waves);
+  auto lds_nodes_for = [&](int per_wave, int waves_per_block, int blocks_per_cu) {
+    int room = (lds_limit / blocks_per_cu - waves_per_block * per_wave) / 208;
+    if (room < 0) room = 0;
+    int n = d->n_nodes < room ? d->n_nodes : room;
+    if (!d->boxes_ordered) n = 0;
+    if (const char *e = getenv("RT_LDS_NODES")) { int v = atoi(e); if (v >= 0 && v < n) n = v; }
+    return n;
+  };
+  const int n_lds_cam = lds_nodes_for(per_wave_cam, wpb_cam, bpc_cam), n_lds_trace = lds_nodes_for(per_wave_trace, wpb_tr, bpc_tr);
+  const int smem_cam = n_lds_cam * 208 + wpb_cam * per_wave_cam;
+  const int smem_trace = n_lds_trace * 208 + wpb_tr * per_wave_trace;
+
+  const int64_t paths = (int64_t)K.n_tiles * 64 * (K.sample_end - K.sample_first);
+  if (wavefront_ensure_queues(d, paths, cam_waves, max_waves) != 0) return -1;
+  K.wf_hit0 = d->wf_hit0; K.wf_hit = d->wf_hit; K.wf_ray[0] = d->wf_ray[0]; K.wf_ray[1] = d->wf_ray[1];
+  K.wf_cnt_hit0 = d->wf_cnt;
+  K.wf_cnt_hit = d->wf_cnt + d->wf_hard0;
+  K.wf_cnt_ray[0] = K.wf_cnt_hit + d->wf_hit_chunks;
+  K.wf_cnt_ray[1] = K.wf_cnt_ray[0] + d->wf_ray_chunks;
+  K.wf_ctl = d->wf_ctl;
+  K.wf_soft_chunks = (int32_t)(d->wf_soft0 > 0x7fffffff ? 0x7fffffff : d->wf_soft0);
+  K.park = nullptr;
+  HIP_TRY(hipMemsetAsync(d->wf_ctl, 0, (size_t)WF_N_CTL * WF_CTL_STRIDE * 4, stream));
+
+  for (int pass = 0; pass < (1 << 20); pass++) {
+    if (pass > 0) HIP_TRY(hipMemsetAsync(d->wf_ctl + WF_STOPPED * WF_CTL_STRIDE, 0, 4, stream));
+    K.n_lds_nodes = n_lds_cam;
+    K.pyr_nodes = n_lds_cam;
+    if (const char *e = getenv("RT_PYRAMID")) { if (atoi(e) == 0) K.pyr_nodes = 0; }
+    K.wf_n_waves = cam_waves;
+    int rc = rt_wf_launch_camera(&K, cam_blocks, geometry_cam, smem_cam, stream);
+    if (rc != 0) return rt_fail("camera kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    for (int b = 0; b < K.max_bounces; b++) {
+      K.wf_bounce = b;
+      K.wf_n_waves = shade_waves;
+      rc = rt_wf_launch_shade(&K, shade_blocks, b == 0, stream);
+      if (rc != 0) return rt_fail("shade kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+      if (b + 1 >= K.max_bounces) break;
+      K.wf_bounce = b + 1;
+      K.wf_n_waves = tr_waves;
+      K.n_lds_nodes = n_lds_trace;
+      unsigned long long *accum_keep = K.accum;
+      if (getenv("RT_WF_NOACC")) K.accum = nullptr;       // experiment: trace kernel without its global atomics (wrong image)
+      rc = rt_wf_launch_trace(&K, tr_blocks, geometry, smem_trace, stream);
+      K.accum = accum_keep;
+      if (rc != 0) return rt_fail("trace kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+      if (b >= 7 && (b & 3) == 3) {
+        // long bounce limits: most paths have ended long before; look at the ray queue the next shade kernel would
+        // read from every fourth bounce and stop launching when a whole bounce produced no hit
+        HIP_TRY(hipMemcpyAsync(d->wf_ctl_host, d->wf_ctl, (size_t)WF_N_CTL * WF_CTL_STRIDE * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (d->wf_ctl_host[WF_HIT_ALLOC * WF_CTL_STRIDE] == 0) break;
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(d->wf_ctl_host, d->wf_ctl, (size_t)WF_N_CTL * WF_CTL_STRIDE * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (d->wf_ctl_host[WF_STOPPED * WF_CTL_STRIDE] == 0) break;
+  }
+  return 0;
+}
+
 static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p, void *d_accum,
                                     hipStream_t stream) {
   if (ensure_device() != 0) return -1;
@@ -967,8 +1097,13 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     g_ws.ev1.push_back(b);
   }
   HIP_TRY(hipEventRecord(g_ws.ev0[slot], stream));
-  int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, stream);
-  if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  const char *pipe = getenv("RT_PIPELINE");
+  if (variant == 5 && pipe && strcmp(pipe, "wf") == 0) {
+    if (launch_wavefront(d, K, stream) != 0) return -1;
+  } else {
+    int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, stream);
+    if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  }
   HIP_TRY(hipEventRecord(g_ws.ev1[slot], stream));
   g_ws.n_timed += 1;
   return 0;

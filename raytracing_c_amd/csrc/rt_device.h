@@ -102,6 +102,29 @@ typedef struct {
   uint32_t *park;              /* tile-stream kernel: [waves][18][128] dwords, hits parked until a dense shade block (nullptr = off) */
   int32_t short_div;           /* 1: leaf blocks take 1 / det from rcp_exact() (host-checked determinant bound), 0: IEEE division */
   int32_t pyr_nodes;           /* node blocks of camera rays on nodes [0, n) test only the children the tile's pyramid can touch; 0 = off */
+  /* wavefront pipeline (rt_wavefront.hip): camera / trace / shade kernels joined by record queues in HBM.  A queue is
+   * an array of chunks of WF_CHUNK records, struct-of-arrays inside a chunk ([field][WF_CHUNK] dwords), plus the number
+   * of records in every chunk; chunks are handed to producing waves by an atomic counter (wf_ctl). */
+  uint32_t *wf_hit0;           /* camera-ray hits: WF_HIT0_FIELDS dwords per record                                     */
+  uint32_t *wf_hit;            /* hits of continuation rays: WF_HIT_FIELDS                                              */
+  uint32_t *wf_ray[2];         /* continuation rays, written by the shade kernel of bounce b into [b & 1]: WF_RAY_FIELDS */
+  uint32_t *wf_cnt_hit0, *wf_cnt_hit, *wf_cnt_ray[2];   /* records per chunk                                            */
+  uint32_t *wf_ctl;            /* WF_CTL_* words, WF_CTL_STRIDE dwords apart                                            */
+  int32_t wf_soft_chunks;      /* camera kernel: a wave that is handed chunk >= this of wf_hit0 stops taking units      */
+  int32_t wf_bounce;           /* shade / trace kernels: bounce index of the records they read                          */
+  int32_t wf_n_waves;          /* waves of this launch (the last one to finish resets the control words it consumed)    */
 } RT_KParams;
+
+#define WF_CHUNK        256
+#define WF_HIT0_FIELDS  9      /* direction (3), t, triangle, u, v, pixel (y << 16 | x), sample                         */
+#define WF_HIT_FIELDS   5      /* index of the ray record (chunk * WF_CHUNK + slot), t, triangle, u, v                  */
+#define WF_RAY_FIELDS   15     /* origin (3), direction (3), tint (3), emission (3), rng, pixel (y << 16 | x), bounce   */
+#define WF_CTL_STRIDE   16     /* one control word per 64-byte line                                                     */
+enum {
+  WF_HIT0_ALLOC = 0, WF_HIT0_HEAD, WF_HIT_ALLOC, WF_HIT_HEAD, WF_RAY0_ALLOC, WF_RAY0_HEAD, WF_RAY1_ALLOC, WF_RAY1_HEAD,
+  WF_STOPPED,      /* set by a camera-kernel wave that ran into wf_soft_chunks: units are left, another pass is needed */
+  WF_DONE_WAVES,   /* waves of the running kernel that have finished                                                   */
+  WF_N_CTL
+};
 
 #endif /* RT_DEVICE_H */
