@@ -23,8 +23,26 @@ extern "C" {
 extern char const *rt_last_error(void);
 extern void        rt_clear_error(void);
 
-/* Selects the HIP device for this process (default 0).  0 on success. */
+/* Selects the HIP device for this process (default 0) and reads the library's configuration -- the environment
+ * variables RT_DEVICES / RT_DEVICES_REHEARSE below, nothing else -- once.  0 on success. */
 extern int rt_init(int device);
+
+/* A frame behind render_thread_proc() / render() / rt_render_frame() is spread over the first `n_devices` GPUs of the
+ * node (primary device, then the following ones): every GPU renders the chunks rt_chunk_owner() gives its rank from its
+ * own copy of the scene, the compact u8 tiles go to the primary GPU with one peer copy per device, which untiles and
+ * fills the caller's pixels (driver.c:793-818 needs no change: its `-T n` threads enter as before, one of them drives
+ * all GPUs).  Default 1, or the environment variable RT_DEVICES read by rt_init().  `rehearse` != 0 (RT_DEVICES_REHEARSE=1)
+ * maps all n logical devices onto the primary GPU -- the N-device code path on a one-GPU machine, for tests.
+ * rt_device_count() = how many GPUs the next frame will use (min(n_devices, GPUs present)). */
+extern int rt_set_devices(i32 n_devices, i32 rehearse);
+extern i32 rt_device_count(void);
+
+/* 0 (default): the tile-stream path kernel.  1: the wavefront pipeline (camera / shade / trace kernels joined by record
+ * queues in HBM, csrc/rt_wavefront.hip): the same images and counters bit for bit, measured slower;
+ * selectable for measurements.  rt_set_wavefront_capacity(): camera-ray hits its queues hold per pass (default 96 M). */
+extern int  rt_set_pipeline(i32 pipeline);
+extern i32  rt_get_pipeline(void);
+extern void rt_set_wavefront_capacity(i64 records);
 
 /* Frame seed of the per-path RNG rule rt_path_seed() (rt_math.h); replaces
  * `random_state = time_now()` of raytracer.c:597.  Default 0x1234ABCD. */
@@ -45,6 +63,12 @@ typedef struct RT_Device_Scene RT_Device_Scene;
 extern RT_Device_Scene *rt_scene_upload(Scene const *scene);
 extern void             rt_scene_release(RT_Device_Scene *dscene);
 extern void             rt_scene_invalidate(Scene const *scene);
+/* render_thread_proc() re-reads, on every frame, the dimensions and base pointers of the host Scene, its material records
+ * and the descriptors of the Images they reference (a few microseconds), and uploads again when any of that changed.  It
+ * does NOT re-read the geometry or texel BYTES: a host that edits those in place calls rt_scene_invalidate().
+ * rt_scene_verify() is the full comparison on demand: 1 = the cached copy still matches the host scene, 0 = it did not
+ * (dropped; the next frame uploads), -1 = nothing cached for this Scene. */
+extern int              rt_scene_verify(Scene const *scene);
 extern i64              rt_scene_device_bytes(RT_Device_Scene const *dscene);
 
 /* Camera used by rt_render_accumulate() for an explicitly uploaded scene;
@@ -137,8 +161,18 @@ extern int rt_render_frame(Scene const *scene, Image const *image, isize samples
                            f32 *linear, u64 *accum);
 
 /* Counters of the last rt_render_accumulate / rt_render_frame on this process
- * (read back synchronously). */
+ * (read back synchronously; summed over the devices of a multi-device frame). */
 extern int rt_get_counters(RT_Counters *out);
+
+/* Where the time of the last frame behind render_thread_proc / render / rt_render_frame went, in milliseconds.
+ * Host clock: stamp = the per-frame scene check, upload = the scene upload when one was needed, enqueue = launching the
+ * frame, total = the whole call.  HIP events on the frame's stream: gpu_prep = accumulator clear + the preparation kernel,
+ * gpu_path = the path kernel, gpu_resolve, gpu_copy = device-to-host copy of the image.  (A multi-device frame reports
+ * total_ms only.) */
+typedef struct {
+  f32 stamp_ms, upload_ms, enqueue_ms, gpu_prep_ms, gpu_path_ms, gpu_resolve_ms, gpu_copy_ms, total_ms;
+} RT_Frame_Timing;
+extern int rt_get_frame_timing(RT_Frame_Timing *out);
 
 /* Diagnostic kernel only (env RT_KERNEL=4): out[0..15] = 8 pairs (times a block ran, lanes it ran with) for
  * shade, environment, regenerate, leaf (uniform), leaf (per lane), node (uniform), node (per lane), pop;
@@ -179,6 +213,19 @@ extern int rt_test_quantize_sweep(u64 out[2]);
  * an uploaded scene: out_t[n], out_tri[n] (-1 = miss), out_uv[2n]. */
 extern int rt_test_trace(RT_Device_Scene *dscene, i32 n, f32 const *rays,
                          f32 *out_t, i32 *out_tri, f32 *out_uv);
+
+/* The same through the PRODUCTION traversal: traversal_blocks() (csrc/rt_dev.hip.h) -- the NODE / LEAF / pop code the path
+ * kernels run -- in the path kernel's launch geometry (16-wave workgroups, tree in LDS), lanes refilled from the ray list as
+ * they finish so that blocks mix rays at different depths as a frame does.
+ *   pyramid    NULL, or 19 floats: 4 outward plane normals at [4 q .. 4 q + 2], the rays' common origin at [16 .. 18]; every
+ *              ray then counts as a camera ray of one tile and node blocks take the pyramid-culled form (node_enter_few)
+ *              where the path kernel would.  The caller guarantees origin and planes hold for every ray.
+ *   exit_lanes 1 .. 64: finished lanes that end a round of blocks (the path kernel uses 48)
+ *   mode       0 = the kernel instance a frame of this scene would use, 1 = IEEE division in the leaf blocks,
+ *              2 = nodes through L1 / L2 instead of the LDS copy
+ *   visits     [0] += 8-box tests (raytracer.c:452), [1] += 8-triangle tests (raytracer.c:476) */
+extern int rt_test_trace_stream(RT_Device_Scene *dscene, i32 n, f32 const *rays, f32 const *pyramid, i32 exit_lanes, i32 mode,
+                                f32 *out_t, i32 *out_tri, f32 *out_uv, u64 visits[2]);
 
 /* Bilinear fetch (driver.c:49-93) of n (u,v) pairs on texture `tex` of the
  * uploaded scene (index in upload order; -1 = background image). */

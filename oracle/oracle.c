@@ -783,6 +783,14 @@ void oracle_trace_rays(Scene const *scene, i32 n, f32 const *rays, f32 *out_t, i
   }
 }
 
+/* oracle_trace_rays + the node / leaf visits those rays cost (ray_aabbs_hit_8 / ray_triangles_hit_8 calls, raytracer.c:452,476) */
+void oracle_trace_rays_counted(Scene const *scene, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv, u64 visits[2]) {
+  u64 n0 = tl_counters.node_visits, l0 = tl_counters.leaf_visits;
+  oracle_trace_rays(scene, n, rays, out_t, out_tri, out_uv);
+  visits[0] = tl_counters.node_visits - n0;
+  visits[1] = tl_counters.leaf_visits - l0;
+}
+
 void oracle_sample_texture_bilinear(Image const *texture, f32 u, f32 v, f32 rgb[3]) {
   rt_v3 c = sample_texture_bilinear(texture, u, v);
   rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;

@@ -95,6 +95,8 @@ bool oracle_ray_triangles_hit_8(Ray const *ray, Triangles const *tris, isize off
 void oracle_ray_scene_hit(Ray const *ray, Scene const *scene, Hit *hit, i32 *triangle);                     /* raytracer.c:443-503 */
 /* batch closest hit: out_uv = barycentrics (t1, t2) of the accepted triangle (raytracer.c:164-165) */
 void oracle_trace_rays(Scene const *scene, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv);
+/* ... and the node / leaf visits they cost in total: visits[0] = ray_aabbs_hit_8 calls, visits[1] = ray_triangles_hit_8 calls */
+void oracle_trace_rays_counted(Scene const *scene, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv, u64 visits[2]);
 void oracle_sample_texture_bilinear(Image const *texture, f32 u, f32 v, f32 rgb[3]);                        /* driver.c:49-93 */
 void oracle_sample_background(Image const *image, f32 const dir[3], f32 rgb[3]);                            /* driver.c:95-104 */
 /* driver.c:287-348: returns brdf rgba, writes out_dir; *state is the RNG state */

@@ -2,15 +2,22 @@
 // (raytracer.h:51-56) and the device-control calls of include/rt_hip.h.
 //
 // Nothing in this file computes a pixel on the CPU: every entry point either
-// drives the gfx950 kernels of rt_kernels.hip or fails with rt_last_error().
+// drives the gfx950 kernels of rt_kernels.hip / rt_wavefront.hip or fails with rt_last_error().
+//
+// State is kept PER DEVICE (struct Device): HIP context, workspace, scene cache, launch timing.  Slot 0 is the
+// process's primary device (rt_init); slots 1 .. N-1 exist when a frame behind render_thread_proc / render() is spread
+// over N GPUs (RT_DEVICES, rt_set_devices).  The product library reads its configuration ONCE (config()); the RT_*
+// experiment knobs of earlier rounds exist only in the diagnostic build (-DRT_DIAG_VARIANTS, librt_hip_diag.so).
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <algorithm>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -22,6 +29,8 @@
 // launchers in rt_kernels.hip
 extern "C" {
 int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream);
+int rt_launch_prepare(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, unsigned long long *counters, uint32_t *work_head,
+                      uint32_t *cost_cur, const uint32_t *cost_prev, uint32_t *order, hipStream_t stream);
 int rt_launch_resolve(int width, int height, int samples, int chunks_x, const int32_t *local_chunks, int n_local_chunks,
                       const unsigned long long *accum, uint8_t *tiles, uint8_t *image, float *linear,
                       hipStream_t stream);
@@ -33,13 +42,16 @@ int rt_launch_test_srgb_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_quantize_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_trace(const RT_KParams *P, int n, const float *rays, float *out_t, int *out_tri, float *out_uv,
                          hipStream_t stream);
+int rt_launch_test_trace_stream(const RT_KParams *P, int n, const float *rays, const float *pyr, int exit_lanes, int n_blocks,
+                                int smem_bytes, float *out_t, int *out_tri, float *out_uv, unsigned long long *visits,
+                                hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
 int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int lw, int lh, int stride, int comp,
                        int samples, int *owner, uint8_t *pixels, hipStream_t stream);
-int rt_launch_stream_init(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, hipStream_t stream);
-int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
+int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
+                           hipStream_t stream);
 // rt_wavefront.hip
 int rt_wf_launch_camera(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream);
 int rt_wf_launch_trace(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream);
@@ -74,12 +86,6 @@ extern "C" void rt_clear_error(void) {
     if (e_ != hipSuccess) return rt_fail("%s failed: %s", #expr, hipGetErrorString(e_));      \
   } while (0)
 
-#define HIP_TRY_NULL(expr)                                                                    \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess) { rt_fail("%s failed: %s", #expr, hipGetErrorString(e_)); return nullptr; } \
-  } while (0)
-
 // Temporary device buffer that is released on every exit path (HIP_TRY returns early).
 struct DevBuf {
   void *p = nullptr;
@@ -91,14 +97,93 @@ struct DevBuf {
   template <typename T> T *as() const { return (T *)p; }
 };
 
-// ---------------------------------------------------------------------------------
-// process state
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
-static std::mutex g_mutex;          // serialises frames and the scene cache
-static int        g_device = 0;
-static bool       g_device_ready = false;
-static int        g_num_cus = 0;
-static u32        g_seed = 0x1234ABCDu;
+// ---------------------------------------------------------------------------------
+// configuration: read once, never per launch
+//
+// Product library: RT_DEVICES (GPUs a frame behind render_thread_proc / render() is spread over, default 1) and
+// RT_DEVICES_REHEARSE (=1: the N logical devices all map onto the primary GPU -- what a one-GPU box can run of the
+// N-GPU path), overridable by rt_set_devices().  Nothing else in the environment changes what the library does.
+// Diagnostic library (-DRT_DIAG_VARIANTS): the experiment knobs of earlier rounds (RT_KERNEL, RT_SCHED_THRESH, ...),
+// read at every launch so that one process can A/B them (tools/exp_kernels.py, tests/test_gpu_diag.py).
+
+#ifdef RT_DIAG_VARIANTS
+static int knob_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static bool knob_is(const char *name, const char *value) {
+  const char *e = getenv(name);
+  return e && strcmp(e, value) == 0;
+}
+static bool knob_set(const char *name) { return getenv(name) != nullptr; }
+#else
+static inline int knob_int(const char *, int dflt) { return dflt; }
+static inline bool knob_is(const char *, const char *) { return false; }
+static inline bool knob_set(const char *) { return false; }
+#endif
+
+#define RT_MAX_DEVICES 16
+
+struct Config {
+  int  devices = 1;
+  bool rehearse = false;
+};
+static std::mutex g_cfg_mutex;
+static Config &config_locked() {
+  static Config c = [] {
+    Config c0;
+    if (const char *e = getenv("RT_DEVICES")) {
+      int v = atoi(e);
+      if (v >= 1 && v <= RT_MAX_DEVICES) c0.devices = v;
+    }
+    if (const char *e = getenv("RT_DEVICES_REHEARSE")) c0.rehearse = atoi(e) != 0;
+    return c0;
+  }();
+  return c;
+}
+static Config config() {
+  std::lock_guard<std::mutex> lock(g_cfg_mutex);
+  return config_locked();
+}
+
+extern "C" int rt_set_devices(i32 n_devices, i32 rehearse) {
+  if (n_devices < 1 || n_devices > RT_MAX_DEVICES) return rt_fail("rt_set_devices: %d outside [1, %d]", n_devices, RT_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_cfg_mutex);
+  Config &c = config_locked();
+  c.devices = n_devices;
+  c.rehearse = rehearse != 0;
+  return 0;
+}
+
+// 0 = tile-stream path kernel (the product's kernel), 1 = wavefront pipeline (rt_wavefront.hip: same images and counters,
+// measured slower -- kept selectable for measurements and for its queue-driven trace kernel)
+static std::atomic<int>     g_pipeline{0};
+static std::atomic<int64_t> g_wf_cap_records{(int64_t)96 << 20};
+
+extern "C" int rt_set_pipeline(i32 pipeline) {
+  if (pipeline != 0 && pipeline != 1) return rt_fail("rt_set_pipeline: %d is not 0 (tile stream) or 1 (wavefront)", pipeline);
+  g_pipeline.store(pipeline);
+  return 0;
+}
+extern "C" i32 rt_get_pipeline(void) { return g_pipeline.load(); }
+extern "C" void rt_set_wavefront_capacity(i64 records) {
+  if (records >= 1024) g_wf_cap_records.store(records);
+}
+
+// ---------------------------------------------------------------------------------
+// per-device state
+
+struct Partition;
+struct RT_Device_Scene;
+
+struct FrameTiming {          // the most recent frame through render_thread_proc / render / rt_render_frame
+  float stamp_ms = 0, upload_ms = 0, enqueue_ms = 0, gpu_prep_ms = 0, gpu_path_ms = 0, gpu_resolve_ms = 0, gpu_copy_ms = 0,
+        total_ms = 0;
+};
 
 struct Workspace {
   unsigned long long *accum = nullptr;
@@ -106,42 +191,103 @@ struct Workspace {
   uint8_t            *image = nullptr;
   float              *linear = nullptr;
   size_t              image_pixels = 0;
+  uint8_t            *tiles = nullptr;        // multi-device frames: this device's compact tiles
+  size_t              tiles_bytes = 0;
+  uint8_t            *all_tiles = nullptr;    // slot 0: the tiles of every device, rank-major
+  size_t              all_tiles_bytes = 0;
   // HIP event pairs around every path-kernel launch since the last timing reset
   std::vector<hipEvent_t> ev0, ev1;
   size_t              n_timed = 0;
-  unsigned long long *wave_times = nullptr;   // diagnostic kernel (RT_KERNEL=4)
+  hipEvent_t          ev_frame[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // frame start, prep done, path done, resolve done, copy done
+  unsigned long long *wave_times = nullptr;   // diagnostic kernel (RT_KERNEL=4) / RT_WAVE_TIMES
   int                 wave_times_n = 0;
 };
 #define RT_MAX_TIMED 256
-static Workspace g_ws;
-static unsigned long long *g_last_counters = nullptr;   // counters of the most recent path-kernel launch
 
-static int ensure_device() {
-  if (g_device_ready) return 0;
+struct DevPartition {
+  const Partition        *host = nullptr;
+  std::vector<int32_t *>  d_lists;            // device copies of the ranks' chunk lists, uploaded on first use
+  int32_t                *d_owner_slot = nullptr;
+};
+
+struct Device {
+  int        slot = 0, phys = 0;
+  bool       ready = false;
+  int        num_cus = 0;
+  std::mutex mutex;                           // serialises frames, the scene cache and the workspace of this device
+  Workspace  ws;
+  unsigned long long *last_counters = nullptr;   // counters of the most recent path-kernel launch
+  std::unordered_map<const Scene *, RT_Device_Scene *> scene_cache;
+  std::unordered_map<RT_Device_Scene *, Camera>        cameras;
+  std::vector<DevPartition>                            parts;   // guarded by g_partition_mutex
+  FrameTiming timing;
+};
+
+static Device g_devs[RT_MAX_DEVICES];
+static int    g_primary = 0;                   // physical device of slot 0
+static bool   g_primary_fixed = false;         // slot 0 has been initialised (rt_init can no longer move it)
+static std::atomic<u32> g_seed{0x1234ABCDu};
+static std::mutex g_multi_mutex;               // counters of the last multi-device frame
+static RT_Counters g_multi_counters;
+static bool        g_multi_counters_valid = false;
+
+static Device &dev0() { return g_devs[0]; }
+
+// Makes `D`'s GPU the calling thread's current HIP device for the guard's lifetime.
+struct DeviceGuard {
+  int  prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const Device &D) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != D.phys) switched = hipSetDevice(D.phys) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+static int ensure_device(Device &D) {            // D.mutex held (or single-threaded start-up)
+  if (D.ready) return hipSetDevice(D.phys) == hipSuccess ? 0 : rt_fail("hipSetDevice(%d) failed", D.phys);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
     return rt_fail("no HIP device available (%s); the render path has no CPU fallback",
                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
   }
-  if (g_device >= count) return rt_fail("device %d requested but only %d present", g_device, count);
-  HIP_TRY(hipSetDevice(g_device));
+  if (D.slot == 0) {
+    D.phys = g_primary;
+    g_primary_fixed = true;
+  } else {
+    D.phys = config().rehearse ? g_primary : (g_primary + D.slot) % count;
+  }
+  if (D.phys >= count) return rt_fail("device %d requested but only %d present", D.phys, count);
+  HIP_TRY(hipSetDevice(D.phys));
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
-  g_num_cus = prop.multiProcessorCount;
-  g_device_ready = true;
+  HIP_TRY(hipGetDeviceProperties(&prop, D.phys));
+  D.num_cus = prop.multiProcessorCount;
+  D.ready = true;
   return 0;
 }
 
 extern "C" int rt_init(int device) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (g_device_ready && device != g_device) return rt_fail("rt_init: device already initialised as %d", g_device);
-  g_device = device;
-  return ensure_device();
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (g_primary_fixed && device != g_primary) return rt_fail("rt_init: device already initialised as %d", g_primary);
+  if (device < 0) return rt_fail("rt_init: device %d is invalid", device);
+  g_primary = device;
+  for (int i = 0; i < RT_MAX_DEVICES; i++) g_devs[i].slot = i;
+  (void)config();                                 // the one read of the environment
+  return ensure_device(D);
 }
 
-extern "C" void rt_set_seed(u32 seed) { g_seed = seed; }
-extern "C" u32  rt_get_seed(void) { return g_seed; }
+// GPUs a frame behind render_thread_proc / render() will be spread over on this machine right now
+extern "C" i32 rt_device_count(void) {
+  Config c = config();
+  if (c.rehearse) return c.devices;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return 0;
+  return c.devices < count ? c.devices : count;
+}
+
+extern "C" void rt_set_seed(u32 seed) { g_seed.store(seed); }
+extern "C" u32  rt_get_seed(void) { return g_seed.load(); }
 
 // ---------------------------------------------------------------------------------
 // material tokens (rt_materials.h): recognised by address, not callable
@@ -167,6 +313,7 @@ extern "C" Color3 sample_background(Image const *, Vec3) {
 // scene residency
 
 struct RT_Device_Scene {
+  Device      *dev = nullptr;
   float       *nodes = nullptr;
   float       *leaves = nullptr;
   float       *tris = nullptr;
@@ -178,8 +325,10 @@ struct RT_Device_Scene {
   int64_t      bytes = 0;
   float        max_edge = 0.0f;   // largest |component| of an edge b - a, c - a in the leaf tiles (NaN if one is NaN)
   bool         boxes_ordered = true;      // every child box of every node has min <= max on every axis (no NaN either)
-  // fingerprint of the host scene this was built from (scene_fingerprint)
-  uint64_t     fp = 0;
+  // what the host Scene looked like at upload: the per-frame stamp (scene_stamp) re-reads exactly this much of it
+  uint64_t     stamp = 0;
+  std::vector<const void *> mat_ptrs;     // distinct shader.data pointers, upload order
+  std::vector<int32_t>      mat_first_tri;   // a triangle that uses mat_ptrs[k]
   // launch state of this device scene: two device scenes can have launches in flight on two streams at once
   unsigned long long *counters = nullptr;      // RT_N_COUNTERS
   uint32_t           *work_head = nullptr;
@@ -196,15 +345,13 @@ struct RT_Device_Scene {
   int32_t             wf_waves = 0;            // waves the capacities were sized for
   // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
   uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
-  uint32_t    *order = nullptr, *hist = nullptr;
+  uint32_t    *order = nullptr;
   int32_t      sched_tiles = 0, sched_cur = 0;
   bool         sched_valid = false;            // cost[cur^1] holds the costs of a launch with sched_key
   uint64_t     sched_key = 0;
 };
 
-static std::unordered_map<const Scene *, RT_Device_Scene *> g_scene_cache;
-
-static void free_device_scene(RT_Device_Scene *d) {
+static void free_device_scene(RT_Device_Scene *d) {      // d->dev->mutex held, d's device current
   if (!d) return;
   (void)hipFree(d->nodes);
   (void)hipFree(d->leaves);
@@ -212,7 +359,7 @@ static void free_device_scene(RT_Device_Scene *d) {
   (void)hipFree(d->mats);
   (void)hipFree(d->textures);
   (void)hipFree(d->texels);
-  if (g_last_counters == d->counters) g_last_counters = nullptr;
+  if (d->dev && d->dev->last_counters == d->counters) d->dev->last_counters = nullptr;
   (void)hipFree(d->counters);
   (void)hipFree(d->work_head);
   (void)hipFree(d->tile_next);
@@ -227,7 +374,6 @@ static void free_device_scene(RT_Device_Scene *d) {
   (void)hipFree(d->cost[0]);
   (void)hipFree(d->cost[1]);
   (void)hipFree(d->order);
-  (void)hipFree(d->hist);
   delete d;
 }
 
@@ -272,9 +418,6 @@ static int texture_index(Image const *img, TexturePool &pool) {
   return idx;
 }
 
-extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
-                                      hipStream_t stream);
-
 static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t *bytes) {
   size_t n = pool.texels ? pool.texels * 4 : 16;
   HIP_TRY(hipMalloc((void **)d_texels, n));
@@ -301,14 +444,19 @@ static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t
   return 0;
 }
 
-// ---- content stamp of a host Scene -------------------------------------------------------------------------
-// render_thread_proc / render / lightmap_bake keep one device copy per Scene* and must notice when the host
-// scene changed underneath it -- the reference reads the live Scene every frame.  The stamp covers, in full:
-// the BVH nodes, the whole triangle block (coordinates + AoS records incl. shader pointers), every distinct
-// PBR_Shader_Data record, and the descriptor (pointer, size, layout) of every Image a material or the background
-// references; of the texel data of images above 64 KB it covers every 61st 8-byte word (50 MB of textures would
-// cost 6 ms per frame in full), which catches a reloaded or regenerated image but not a single edited texel: after such an edit the
-// host calls rt_scene_invalidate().  ~5 MB at ~10 GB/s: 0.5 ms per frame for the helmet.
+
+// ---- stamps of a host Scene ---------------------------------------------------------------------------------
+// render_thread_proc / render / lightmap_bake keep one device copy per Scene* and must notice when the host scene
+// changed underneath it -- the reference reads the live Scene every frame.  Two levels:
+//  * scene_stamp(), paid on EVERY frame (a few microseconds): the dimensions and base pointers of the BVH and the
+//    triangle block, the background proc and Image, every distinct material record (PBR_Shader_Data, 80 bytes) and the
+//    descriptor (pointer, size, layout) of every Image a material references.  A rebuilt, reloaded or re-materialed
+//    scene, a changed material parameter and a swapped texture are all noticed.
+//  * What it does NOT read: the geometry bytes (nodes, coordinates, AoS records) and the texel bytes -- 5 MB + 50 MB for
+//    the helmet, 0.5 ms per frame even when sampled.  A host that edits those IN PLACE, keeping every pointer and size,
+//    calls rt_scene_invalidate(scene) afterwards; scene_init / scene_init_sah / scene_init_gpu /
+//    scene_load_bytes do that themselves.  scene_fingerprint() -- everything, texels of large images sampled -- is what
+//    rt_scene_verify() compares for a host that wants the check anyway.
 static inline uint64_t mix64(uint64_t h, uint64_t v) {
   h ^= v;
   h *= 0x9E3779B97F4A7C15ull;
@@ -348,6 +496,7 @@ static uint64_t hash_image(uint64_t h, Image const *img) {
   }
   return h;
 }
+
 
 static uint64_t scene_fingerprint(Scene const *scene) {
   const Triangles &T = scene->triangles;
@@ -389,14 +538,47 @@ static uint64_t scene_fingerprint(Scene const *scene) {
   return h;
 }
 
+
+static uint64_t hash_image_desc(uint64_t h, Image const *img) {
+  if (!img) return mix64(h, 0x1234u);
+  int64_t desc[6] = {(int64_t)img->components, (int64_t)img->pixel_type, (int64_t)img->width, (int64_t)img->stride,
+                     (int64_t)img->height, (int64_t)(uintptr_t)img->pixels.data};
+  return hash_bytes(h, desc, sizeof desc);
+}
+
+// `mat_ptrs` / `first_tri`: the distinct material records found at upload and one triangle that uses each.  A material
+// pointer is only dereferenced while that triangle still points at it (a host that replaced its materials has freed
+// the old records).  Returns 0 -- never a valid stamp -- when the scene no longer matches the lists.
+static uint64_t scene_stamp(Scene const *scene, const std::vector<const void *> &mat_ptrs, const std::vector<int32_t> &first_tri) {
+  const Triangles &T = scene->triangles;
+  int64_t head[9] = {(int64_t)scene->bvh.depth, (int64_t)scene->bvh.last_row_offset, (int64_t)scene->bvh.nodes.len, (int64_t)T.len,
+                     (int64_t)(uintptr_t)scene->background.proc, (int64_t)(uintptr_t)scene->background.data,
+                     (int64_t)(uintptr_t)scene->bvh.nodes.data, (int64_t)(uintptr_t)T.x[0], (int64_t)(uintptr_t)T.aos};
+  uint64_t h = hash_bytes(0x452821E638D01377ull, head, sizeof head);
+  if (T.aos)
+    for (size_t k = 0; k < mat_ptrs.size(); k++) {
+      const int32_t i = first_tri[k];
+      if (i < 0 || i >= T.len || T.aos[i].shader.data != mat_ptrs[k]) return 0;
+      const PBR_Shader_Data *m = (const PBR_Shader_Data *)mat_ptrs[k];
+      h = hash_bytes(h, m, sizeof *m);
+      h = mix64(h, (uint64_t)(uintptr_t)T.aos[i].shader.proc);
+      h = hash_image_desc(h, m->texture_albedo);
+      h = hash_image_desc(h, m->texture_normal);
+      h = hash_image_desc(h, m->texture_metal_roughness);
+      h = hash_image_desc(h, m->texture_emission);
+    }
+  if (scene->background.proc == (Background_Proc)sample_background) h = hash_image_desc(h, (Image const *)scene->background.data);
+  return h | 1ull;
+}
+
 static float int_bits(int32_t i) {
   float f;
   memcpy(&f, &i, 4);
   return f;
 }
 
-static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
-  if (ensure_device() != 0) return nullptr;
+static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
+  if (ensure_device(D) != 0) return nullptr;
   if (!scene) { rt_fail("rt_scene_upload: scene is NULL"); return nullptr; }
   const Triangles &T = scene->triangles;
   if (T.len <= 0 || T.len % 8 != 0 || !T.x[0] || !T.aos) {
@@ -426,6 +608,8 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   TexturePool pool;
   std::unordered_map<uint64_t, int>      mat_map;     // (data ptr, kind) -> id
   std::vector<float>                     mats;
+  std::vector<const void *>              mat_ptrs;
+  std::vector<int32_t>                   mat_first_tri;
 
   // triangles + materials
   const int n = T.len;
@@ -467,6 +651,8 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
                        int_bits(kind), 0.0f, 0.0f, 0.0f};
         mats.insert(mats.end(), m, m + 20);
         mat_map[key] = mat;
+        mat_ptrs.push_back(a.shader.data);
+        mat_first_tri.push_back(i);
       }
     }
     float *r = &tris[(size_t)i * 28];
@@ -526,6 +712,7 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   if (bg < 0) { rt_fail("rt_scene_upload: background Image is unusable (need PT_u8, >= 3 components, pixels.len >= stride*height*components)"); return nullptr; }
 
   RT_Device_Scene *d = new RT_Device_Scene();
+  d->dev = &D;
   if (hipMalloc((void **)&d->counters, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void **)&d->work_head, 64) != hipSuccess) {
     rt_fail("rt_scene_upload: out of device memory");
@@ -547,54 +734,87 @@ static RT_Device_Scene *upload_scene_locked(Scene const *scene) {
   d->boxes_ordered = boxes_ordered;
   d->n_materials = (int32_t)(mats.size() / 20);
   d->n_textures = (int32_t)pool.descs.size();
-  d->fp = scene_fingerprint(scene);
+  d->mat_ptrs = mat_ptrs;
+  d->mat_first_tri = mat_first_tri;
+  d->stamp = scene_stamp(scene, d->mat_ptrs, d->mat_first_tri);
   return d;
 }
 
-// Camera of an explicitly uploaded scene: captured at upload, replaced by
-// rt_set_camera().  (render_thread_proc reads the host Scene's camera per frame.)
-static std::unordered_map<RT_Device_Scene *, Camera> g_cameras;
-
+// rt_scene_upload / release / set_camera work on the primary device (one process per GPU under torch.distributed)
 extern "C" RT_Device_Scene *rt_scene_upload(Scene const *scene) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  RT_Device_Scene *d = upload_scene_locked(scene);
-  if (d) g_cameras[d] = scene->camera;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  RT_Device_Scene *d = upload_scene_locked(D, scene);
+  if (d) D.cameras[d] = scene->camera;
   return d;
 }
 
 extern "C" void rt_scene_release(RT_Device_Scene *dscene) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  for (auto it = g_scene_cache.begin(); it != g_scene_cache.end(); ++it) {
-    if (it->second == dscene) { g_scene_cache.erase(it); break; }
+  if (!dscene) return;
+  Device &D = dscene->dev ? *dscene->dev : dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  DeviceGuard guard(D);
+  for (auto it = D.scene_cache.begin(); it != D.scene_cache.end(); ++it) {
+    if (it->second == dscene) { D.scene_cache.erase(it); break; }
   }
-  g_cameras.erase(dscene);
+  D.cameras.erase(dscene);
   free_device_scene(dscene);
 }
 
 extern "C" void rt_scene_invalidate(Scene const *scene) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  auto it = g_scene_cache.find(scene);
-  if (it != g_scene_cache.end()) {
-    free_device_scene(it->second);
-    g_scene_cache.erase(it);
+  for (int i = 0; i < RT_MAX_DEVICES; i++) {
+    Device &D = g_devs[i];
+    std::lock_guard<std::mutex> lock(D.mutex);
+    auto it = D.scene_cache.find(scene);
+    if (it != D.scene_cache.end()) {
+      DeviceGuard guard(D);
+      free_device_scene(it->second);
+      D.scene_cache.erase(it);
+    }
   }
 }
 
 extern "C" i64 rt_scene_device_bytes(RT_Device_Scene const *dscene) { return dscene ? dscene->bytes : 0; }
 
+// Full content check of the cached device copy of `scene` on the primary device: 1 = the host scene still equals what was
+// uploaded (geometry and material bytes in full, texels of large images sampled), 0 = it changed (the copy is dropped,
+// the next frame uploads again), -1 = no cached copy.  The per-frame check is scene_stamp() above.
+static std::unordered_map<const Scene *, uint64_t> g_full_fp;     // guarded by dev0().mutex
+extern "C" int rt_scene_verify(Scene const *scene) {
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  auto it = D.scene_cache.find(scene);
+  if (it == D.scene_cache.end() || !scene) return -1;
+  auto fp = g_full_fp.find(scene);
+  if (fp != g_full_fp.end() && fp->second == scene_fingerprint(scene)) return 1;
+  DeviceGuard guard(D);
+  free_device_scene(it->second);
+  D.scene_cache.erase(it);
+  g_full_fp.erase(scene);
+  return 0;
+}
+
 static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d);
 
-static RT_Device_Scene *cached_scene_locked(Scene const *scene) {
+static RT_Device_Scene *cached_scene_locked(Device &D, Scene const *scene, float *stamp_ms, float *upload_ms) {
   if (!scene) { rt_fail("render: scene is NULL"); return nullptr; }
-  auto it = g_scene_cache.find(scene);
-  if (it != g_scene_cache.end()) {
+  const double t0 = now_ms();
+  auto it = D.scene_cache.find(scene);
+  if (it != D.scene_cache.end()) {
     RT_Device_Scene *d = it->second;
-    if (d->fp == scene_fingerprint(scene)) return d;
+    const bool same = d->stamp == scene_stamp(scene, d->mat_ptrs, d->mat_first_tri);
+    if (stamp_ms) *stamp_ms = (float)(now_ms() - t0);
+    if (same) return d;
     free_device_scene(d);                        // the host scene changed since the upload
-    g_scene_cache.erase(it);
+    D.scene_cache.erase(it);
   }
-  RT_Device_Scene *d = upload_scene_locked(scene);
-  if (d) g_scene_cache[scene] = d;
+  const double t1 = now_ms();
+  RT_Device_Scene *d = upload_scene_locked(D, scene);
+  if (d) {
+    D.scene_cache[scene] = d;
+    if (D.slot == 0) g_full_fp[scene] = scene_fingerprint(scene);
+  }
+  if (upload_ms) *upload_ms = (float)(now_ms() - t1);
   return d;
 }
 
@@ -636,24 +856,36 @@ extern "C" i32 rt_chunk_owner(i32 width, i32 height, i32 world, i32 chunk) {
   return (i32)((cx + (int64_t)partition_step(world) * cy) % world);
 }
 
+
 struct Partition {
   int width = 0, height = 0, world = 0;
   int n_chunks = 0, max_local = 0;
   std::vector<std::vector<int32_t>> lists;      // [rank] -> ascending global chunk indices
   std::vector<int32_t>              owner_slot; // [chunk] -> rank * max_local + slot
-  std::vector<int32_t *>            d_lists;    // device copies, uploaded on first use
-  int32_t                          *d_owner_slot = nullptr;
 };
 static std::vector<Partition *> g_partitions;
-static std::mutex               g_partition_mutex;
+static std::mutex               g_partition_mutex;   // the host tables and every Device::parts
+
+static void drop_device_partitions(const Partition *q) {        // g_partition_mutex held
+  for (int i = 0; i < RT_MAX_DEVICES; i++) {
+    Device &D = g_devs[i];
+    for (size_t k = 0; k < D.parts.size(); k++) {
+      if (D.parts[k].host != q) continue;
+      DeviceGuard guard(D);
+      for (int32_t *ptr : D.parts[k].d_lists) (void)hipFree(ptr);
+      (void)hipFree(D.parts[k].d_owner_slot);
+      D.parts.erase(D.parts.begin() + (long)k);
+      break;
+    }
+  }
+}
 
 static Partition *get_partition(int width, int height, int world) {      // g_partition_mutex held
   for (Partition *q : g_partitions)
     if (q->width == width && q->height == height && q->world == world) return q;
   if (g_partitions.size() >= 16) {              // bounded cache: forget the oldest
     Partition *old = g_partitions.front();
-    for (int32_t *ptr : old->d_lists) (void)hipFree(ptr);
-    (void)hipFree(old->d_owner_slot);
+    drop_device_partitions(old);
     delete old;
     g_partitions.erase(g_partitions.begin());
   }
@@ -661,7 +893,6 @@ static Partition *get_partition(int width, int height, int world) {      // g_pa
   q->width = width; q->height = height; q->world = world;
   q->n_chunks = rt_chunk_count(width, height);
   q->lists.resize((size_t)world);
-  q->d_lists.assign((size_t)world, nullptr);
   for (int c = 0; c < q->n_chunks; c++) q->lists[(size_t)rt_chunk_owner(width, height, world, c)].push_back(c);
   for (auto &l : q->lists) if ((int)l.size() > q->max_local) q->max_local = (int)l.size();
   q->owner_slot.resize((size_t)q->n_chunks);
@@ -695,30 +926,42 @@ extern "C" i32 rt_local_chunk_list(i32 width, i32 height, i32 rank, i32 world, i
   return (i32)l.size();
 }
 
-// device copy of a rank's chunk list / of the owner table (HIP device must be initialised)
-static int device_chunk_list(int width, int height, int rank, int world, const int32_t **d_list, int *n_local) {
+static DevPartition &device_partition(Device &D, const Partition *q) {     // g_partition_mutex held
+  for (DevPartition &dp : D.parts)
+    if (dp.host == q) return dp;
+  DevPartition dp;
+  dp.host = q;
+  dp.d_lists.assign((size_t)q->world, nullptr);
+  D.parts.push_back(dp);
+  return D.parts.back();
+}
+
+// device copy of a rank's chunk list / of the owner table on D (D's GPU is the current device)
+static int device_chunk_list(Device &D, int width, int height, int rank, int world, const int32_t **d_list, int *n_local) {
   std::lock_guard<std::mutex> lock(g_partition_mutex);
   Partition *q = get_partition(width, height, world);
+  DevPartition &dp = device_partition(D, q);
   const std::vector<int32_t> &l = q->lists[(size_t)rank];
-  if (!q->d_lists[(size_t)rank]) {
+  if (!dp.d_lists[(size_t)rank]) {
     int32_t *ptr = nullptr;
     HIP_TRY(hipMalloc((void **)&ptr, l.empty() ? 16 : l.size() * 4));
     if (!l.empty()) HIP_TRY(hipMemcpy(ptr, l.data(), l.size() * 4, hipMemcpyHostToDevice));
-    q->d_lists[(size_t)rank] = ptr;
+    dp.d_lists[(size_t)rank] = ptr;
   }
-  *d_list = q->d_lists[(size_t)rank];
+  *d_list = dp.d_lists[(size_t)rank];
   *n_local = (int)l.size();
   return 0;
 }
 
-static int device_owner_table(int width, int height, int world, const int32_t **d_table, int *n_chunks) {
+static int device_owner_table(Device &D, int width, int height, int world, const int32_t **d_table, int *n_chunks) {
   std::lock_guard<std::mutex> lock(g_partition_mutex);
   Partition *q = get_partition(width, height, world);
-  if (!q->d_owner_slot) {
-    HIP_TRY(hipMalloc((void **)&q->d_owner_slot, q->owner_slot.size() * 4));
-    HIP_TRY(hipMemcpy(q->d_owner_slot, q->owner_slot.data(), q->owner_slot.size() * 4, hipMemcpyHostToDevice));
+  DevPartition &dp = device_partition(D, q);
+  if (!dp.d_owner_slot) {
+    HIP_TRY(hipMalloc((void **)&dp.d_owner_slot, q->owner_slot.size() * 4));
+    HIP_TRY(hipMemcpy(dp.d_owner_slot, q->owner_slot.data(), q->owner_slot.size() * 4, hipMemcpyHostToDevice));
   }
-  *d_table = q->d_owner_slot;
+  *d_table = dp.d_owner_slot;
   *n_chunks = q->n_chunks;
   return 0;
 }
@@ -735,7 +978,7 @@ static int check_params(RT_Render_Params const *p) {
   return 0;
 }
 
-static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p,
+static int fill_kparams(Device &D, RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p,
                         void *d_accum) {
   memset(K, 0, sizeof *K);
   K->nodes = d->nodes;
@@ -769,22 +1012,20 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   K->world = p->world;
   {
     int n_local = 0;
-    if (device_chunk_list(p->width, p->height, p->rank, p->world, &K->local_chunks, &n_local) != 0) return -1;
+    if (device_chunk_list(D, p->width, p->height, p->rank, p->world, &K->local_chunks, &n_local) != 0) return -1;
     K->n_local_chunks = n_local;
   }
   K->sample_first = p->sample_first;
   K->sample_end = p->sample_count > 0 ? p->sample_first + p->sample_count : p->samples;
   int n_samples = K->sample_end - K->sample_first;
-  // samples per work item: the largest of 32 / 16 / 8 that still leaves 24 items per wave (16 waves per CU).  Big
-  // items keep a wave on few pixels and have fewer end-of-item bubbles, small ones balance the end of the launch;
-  // measured on the helmet frame (ms): whole frame 53.3 (16) 52.0 (32) 52.8 (64); 1/2 frame 27.0 (16) 26.7 (32)
-  // 30.1 (64); 1/4 frame 16.0 (8) 15.7 (16) 16.1 (32); 1/8 frame 8.1 (4) 6.9 (8) 7.0 (16) 7.8 (32).
+  // (work items of the diagnostic kernel generations: samples per item = the largest of 32 / 16 / 8 that still leaves 24
+  // items per wave)
   int slab = p->slab;
   if (slab <= 0) {
     slab = 8;
     for (int cand = 32; cand > 8; cand >>= 1) {
       int64_t items = (int64_t)K->n_local_chunks * 16 * ((n_samples + cand - 1) / cand);
-      if (items >= (int64_t)24 * g_num_cus * 16) { slab = cand; break; }
+      if (items >= (int64_t)24 * D.num_cus * 16) { slab = cand; break; }
     }
   }
   int shift = 0;
@@ -800,16 +1041,14 @@ static int fill_kparams(RT_KParams *K, RT_Device_Scene *d, Camera const *cam, RT
   return 0;
 }
 
-
 // ---- wavefront pipeline (rt_wavefront.hip) --------------------------------------------------------------------------
 // Camera kernel -> (shade, trace) per bounce, joined by record queues in HBM.  The queues are sized for `cap` camera-ray
-// hits per pass (grown on demand, never beyond RT_WF_CAP records); a frame with more first hits than that takes several
-// passes: the camera kernel stops taking units when its hit queue is nearly full, the bounces run, and the host -- which
-// reads one control word after every pass -- launches it again; tile_next / work_head keep the position.
-static int64_t g_wf_cap_records = (int64_t)96 << 20;
-
+// hits per pass (grown on demand, never beyond rt_set_wavefront_capacity() records); a frame with more first hits than
+// that takes several passes: the camera kernel stops taking units when its hit queue is nearly full, the bounces run, and
+// the host -- which reads one control word after every pass -- launches it again; tile_next / work_head keep the position.
 static int wavefront_ensure_queues(RT_Device_Scene *d, int64_t paths, int cam_waves, int max_waves) {
-  const int64_t want = paths < g_wf_cap_records ? paths : g_wf_cap_records;
+  const int64_t cap = g_wf_cap_records.load();
+  const int64_t want = paths < cap ? paths : cap;
   // chunks: a closed chunk holds at least WF_CHUNK - 63 records; every wave leaves one open chunk behind
   const int64_t fill = WF_CHUNK - 63;
   const int64_t soft = (want + fill - 1) / fill + cam_waves + 1;
@@ -833,34 +1072,35 @@ static int wavefront_ensure_queues(RT_Device_Scene *d, int64_t paths, int cam_wa
   return 0;
 }
 
-// K: filled for the tile-stream kernel (units, tile counters, schedule feedback, LDS nodes for 16-wave workgroups)
-static int launch_wavefront(RT_Device_Scene *d, RT_KParams &K, hipStream_t stream) {
-  int geometry = 0;
-  if (const char *e = getenv("RT_WF_GEOMETRY")) { geometry = atoi(e); if (geometry < 0 || geometry > 2) geometry = 0; }
-  int geometry_cam = geometry;
-  if (const char *e = getenv("RT_WF_GEOMETRY_CAM")) { geometry_cam = atoi(e); if (geometry_cam < 0 || geometry_cam > 2) geometry_cam = 0; }
-  if (const char *e = getenv("RT_WF_CAP")) { long long v = atoll(e); if (v >= 1024) g_wf_cap_records = v; }
+// K: filled for the tile-stream kernel (units, tile counters, schedule feedback)
+static int launch_wavefront(Device &D, RT_Device_Scene *d, RT_KParams &K, hipStream_t stream) {
+  if (K.width > 65535 || K.height > 65535) return rt_fail("the wavefront pipeline packs a pixel into 16 + 16 bits: %dx%d is too large", K.width, K.height);
+  int geometry = knob_int("RT_WF_GEOMETRY", 0);
+  if (geometry < 0 || geometry > 2) geometry = 0;
+  int geometry_cam = knob_int("RT_WF_GEOMETRY_CAM", geometry);
+  if (geometry_cam < 0 || geometry_cam > 2) geometry_cam = 0;
   const int lds_limit = 160 * 1024;
   static const int wpb_of[3] = {16, 12, 10}, bpc_of[3] = {1, 2, 2};
   const int wpb_cam = wpb_of[geometry_cam], bpc_cam = bpc_of[geometry_cam], wpb_tr = wpb_of[geometry], bpc_tr = bpc_of[geometry];
-  const int per_wave_cam = (K.depth > 0 ? K.depth : 1) * 256 + 1536, per_wave_trace = per_wave_cam;   // perm stack + accumulator tile
-  const int cam_blocks = g_num_cus * bpc_cam, cam_waves = cam_blocks * wpb_cam;
-  const int tr_blocks = g_num_cus * bpc_tr, tr_waves = tr_blocks * wpb_tr;
-  int shade_blocks_per_cu = 5;
-  if (const char *e = getenv("RT_WF_SHADE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 8) shade_blocks_per_cu = v; }
-  const int shade_blocks = g_num_cus * shade_blocks_per_cu, shade_waves = shade_blocks * 4;
+  const int per_wave = (K.depth > 0 ? K.depth : 1) * 256 + 1536;                   // perm stack + accumulator tile
+  const int cam_blocks = D.num_cus * bpc_cam, cam_waves = cam_blocks * wpb_cam;
+  const int tr_blocks = D.num_cus * bpc_tr, tr_waves = tr_blocks * wpb_tr;
+  int shade_blocks_per_cu = knob_int("RT_WF_SHADE_BLOCKS", 5);
+  if (shade_blocks_per_cu < 1 || shade_blocks_per_cu > 8) shade_blocks_per_cu = 5;
+  const int shade_blocks = D.num_cus * shade_blocks_per_cu, shade_waves = shade_blocks * 4;
   const int max_waves = std::max(std::max(cam_waves, tr_waves), shade_waves);
-  auto lds_nodes_for = [&](int per_wave, int waves_per_block, int blocks_per_cu) {
+  auto lds_nodes_for = [&](int waves_per_block, int blocks_per_cu) {
     int room = (lds_limit / blocks_per_cu - waves_per_block * per_wave) / 208;
     if (room < 0) room = 0;
     int n = d->n_nodes < room ? d->n_nodes : room;
     if (!d->boxes_ordered) n = 0;
-    if (const char *e = getenv("RT_LDS_NODES")) { int v = atoi(e); if (v >= 0 && v < n) n = v; }
+    int v = knob_int("RT_LDS_NODES", n);
+    if (v >= 0 && v < n) n = v;
     return n;
   };
-  const int n_lds_cam = lds_nodes_for(per_wave_cam, wpb_cam, bpc_cam), n_lds_trace = lds_nodes_for(per_wave_trace, wpb_tr, bpc_tr);
-  const int smem_cam = n_lds_cam * 208 + wpb_cam * per_wave_cam;
-  const int smem_trace = n_lds_trace * 208 + wpb_tr * per_wave_trace;
+  const int n_lds_cam = lds_nodes_for(wpb_cam, bpc_cam), n_lds_trace = lds_nodes_for(wpb_tr, bpc_tr);
+  const int smem_cam = n_lds_cam * 208 + wpb_cam * per_wave;
+  const int smem_trace = n_lds_trace * 208 + wpb_tr * per_wave;
 
   const int64_t paths = (int64_t)K.n_tiles * 64 * (K.sample_end - K.sample_first);
   if (wavefront_ensure_queues(d, paths, cam_waves, max_waves) != 0) return -1;
@@ -877,8 +1117,7 @@ static int launch_wavefront(RT_Device_Scene *d, RT_KParams &K, hipStream_t strea
   for (int pass = 0; pass < (1 << 20); pass++) {
     if (pass > 0) HIP_TRY(hipMemsetAsync(d->wf_ctl + WF_STOPPED * WF_CTL_STRIDE, 0, 4, stream));
     K.n_lds_nodes = n_lds_cam;
-    K.pyr_nodes = n_lds_cam;
-    if (const char *e = getenv("RT_PYRAMID")) { if (atoi(e) == 0) K.pyr_nodes = 0; }
+    K.pyr_nodes = knob_int("RT_PYRAMID", 1) ? n_lds_cam : 0;
     K.wf_n_waves = cam_waves;
     int rc = rt_wf_launch_camera(&K, cam_blocks, geometry_cam, smem_cam, stream);
     if (rc != 0) return rt_fail("camera kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -891,14 +1130,11 @@ static int launch_wavefront(RT_Device_Scene *d, RT_KParams &K, hipStream_t strea
       K.wf_bounce = b + 1;
       K.wf_n_waves = tr_waves;
       K.n_lds_nodes = n_lds_trace;
-      unsigned long long *accum_keep = K.accum;
-      if (getenv("RT_WF_NOACC")) K.accum = nullptr;       // experiment: trace kernel without its global atomics (wrong image)
       rc = rt_wf_launch_trace(&K, tr_blocks, geometry, smem_trace, stream);
-      K.accum = accum_keep;
       if (rc != 0) return rt_fail("trace kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
       if (b >= 7 && (b & 3) == 3) {
-        // long bounce limits: most paths have ended long before; look at the ray queue the next shade kernel would
-        // read from every fourth bounce and stop launching when a whole bounce produced no hit
+        // long bounce limits: most paths have ended long before; every fourth bounce look at the hit queue the next shade
+        // kernel would read and stop launching when a whole bounce produced no hit
         HIP_TRY(hipMemcpyAsync(d->wf_ctl_host, d->wf_ctl, (size_t)WF_N_CTL * WF_CTL_STRIDE * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (d->wf_ctl_host[WF_HIT_ALLOC * WF_CTL_STRIDE] == 0) break;
@@ -911,37 +1147,33 @@ static int launch_wavefront(RT_Device_Scene *d, RT_KParams &K, hipStream_t strea
   return 0;
 }
 
-static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p, void *d_accum,
-                                    hipStream_t stream) {
-  if (ensure_device() != 0) return -1;
+// Enqueues one launch of the path tracer for p's rank / sample range.  D.mutex held, D's GPU current.
+// ev_prep (optional): recorded between the per-launch preparation and the path kernel.
+static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p, void *d_accum,
+                                    hipStream_t stream, hipEvent_t ev_prep = nullptr) {
+  if (ensure_device(D) != 0) return -1;
   if (check_params(p) != 0) return -1;
   if (!d || !d_accum) return rt_fail("rt_render_accumulate: NULL scene or accumulation buffer");
+  if (d->dev != &D) return rt_fail("rt_render_accumulate: the scene was uploaded to another device");
   RT_KParams K;
-  if (fill_kparams(&K, d, cam, p, d_accum) != 0) return -1;
-  HIP_TRY(hipMemsetAsync(d->counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
-  HIP_TRY(hipMemsetAsync(d->work_head, 0, 64, stream));
-  g_last_counters = d->counters;
-  if (K.n_work == 0) return 0;
-  // persistent grid: 16 waves per CU (4 per SIMD at <= 128 VGPRs), never more waves than work items
-  int waves_per_cu = 16;
-  if (const char *e = getenv("RT_WAVES_PER_CU")) {
-    int v = atoi(e);
-    if (v > 0) waves_per_cu = v;
-  }
-  int n_waves = g_num_cus * waves_per_cu;
-  if (n_waves > K.n_work) n_waves = K.n_work;
-  // 1 plain while-while, 2 phase-scheduled, 3 phase-scheduled + top of the BVH in LDS, 4 = 3 + block statistics,
-  // 5 tile streams (per-tile chunk counters, work joining, inner traversal loop) + top of the BVH in LDS
-  int variant = 5;
-  if (const char *e = getenv("RT_KERNEL")) variant = atoi(e);
+  if (fill_kparams(D, &K, d, cam, p, d_accum) != 0) return -1;
+  D.last_counters = d->counters;
+  // 5 = the tile-stream kernel (the product's only generation); 1-4 exist in the diagnostic build
+  int variant = knob_int("RT_KERNEL", 5);
   if (variant < 1 || variant > 5) variant = 5;
-  K.sched_thresh = 48;
-  if (const char *e = getenv("RT_SCHED_THRESH")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= 64) K.sched_thresh = v;
-  }
-  // dynamic LDS per workgroup: per wave (perm stack: depth x 256 B, accumulator tile: 1536 B) and, for
-  // variant 3, as many leading BVH nodes (level order) as fit in the 160 KB of a CU at 208 B each
+  int pipeline = g_pipeline.load();
+  if (knob_is("RT_PIPELINE", "wf")) pipeline = 1;
+  if (variant != 5) pipeline = 0;
+
+  // persistent grid: 16 waves per CU (4 per SIMD at <= 128 VGPRs), never more waves than work items
+  int waves_per_cu = knob_int("RT_WAVES_PER_CU", 16);
+  if (waves_per_cu <= 0) waves_per_cu = 16;
+  int n_waves = D.num_cus * waves_per_cu;
+  if (n_waves > K.n_work && K.n_work > 0) n_waves = K.n_work;
+  K.sched_thresh = knob_int("RT_SCHED_THRESH", 48);
+  if (K.sched_thresh < 1 || K.sched_thresh > 64) K.sched_thresh = 48;
+  // dynamic LDS per workgroup: per wave (perm stack: depth x 256 B, accumulator tile: 1536 B) and as many leading BVH
+  // nodes (level order) as fit in the 160 KB of a CU at 208 B each
   const int lds_limit = 160 * 1024;
   int per_wave = (K.depth > 0 ? K.depth : 1) * 256 + 1536;
   int smem = 0;
@@ -954,19 +1186,18 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     if (room < 0) room = 0;
     K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
     if (variant == 5 && !d->boxes_ordered) K.n_lds_nodes = 0;      // (the tile-stream kernel's LDS node blocks assume min <= max)
-    if (const char *e = getenv("RT_LDS_NODES")) {
-      int v = atoi(e);
-      if (v >= 0 && v < K.n_lds_nodes) K.n_lds_nodes = v;
-    }
+    int v = knob_int("RT_LDS_NODES", K.n_lds_nodes);
+    if (v >= 0 && v < K.n_lds_nodes) K.n_lds_nodes = v;
     smem = K.n_lds_nodes * 208 + waves_per_block * per_wave;
   }
 
-  // ---- schedule feedback (phase-scheduled kernels only): visit expensive tiles first ----
+  // ---- schedule feedback: visit expensive tiles first (costs = rays per tile of the previous launch of this view) ----
   K.order = nullptr;
   K.tile_cost = nullptr;
-  const char *order_mode = getenv("RT_ORDER");           // "lpt" (default) | "identity"
-  if (variant != 1 && !(order_mode && strcmp(order_mode, "identity") == 0)) {
-    int n_tiles = K.n_local_chunks * 16;
+  K.n_tiles = K.n_local_chunks * 16;
+  const uint32_t *cost_prev = nullptr;
+  if (variant != 1 && !knob_is("RT_ORDER", "identity") && K.n_tiles > 0) {
+    const int n_tiles = K.n_tiles;
     // the costs of a launch are reusable by a launch of the same view, partition and bounce limit
     uint64_t key = 1469598103934665603ull;
     auto mix = [&key](const void *ptr, size_t n) {
@@ -978,22 +1209,19 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     int32_t ids[6] = {K.width, K.height, K.rank, K.world, K.max_bounces, n_tiles};
     mix(ids, sizeof ids);
     if (d->sched_tiles != n_tiles) {
-      (void)hipFree(d->cost[0]); (void)hipFree(d->cost[1]); (void)hipFree(d->order); (void)hipFree(d->hist);
-      d->cost[0] = d->cost[1] = d->order = d->hist = nullptr;
+      (void)hipFree(d->cost[0]); (void)hipFree(d->cost[1]); (void)hipFree(d->order);
+      d->cost[0] = d->cost[1] = d->order = nullptr;
       d->sched_tiles = 0;
       d->sched_valid = false;
       HIP_TRY(hipMalloc(&d->cost[0], (size_t)n_tiles * 4));
       HIP_TRY(hipMalloc(&d->cost[1], (size_t)n_tiles * 4));
       HIP_TRY(hipMalloc(&d->order, (size_t)n_tiles * 4));
-      HIP_TRY(hipMalloc(&d->hist, 1024));
       d->sched_tiles = n_tiles;
     }
     if (d->sched_valid && d->sched_key == key) {
-      int rc2 = rt_launch_tile_order(n_tiles, d->cost[d->sched_cur ^ 1], d->hist, d->order, stream);
-      if (rc2 != 0) return rt_fail("tile order kernels failed: %s", hipGetErrorString((hipError_t)rc2));
+      cost_prev = d->cost[d->sched_cur ^ 1];
       K.order = d->order;
     }
-    HIP_TRY(hipMemsetAsync(d->cost[d->sched_cur], 0, (size_t)n_tiles * 4, stream));
     K.tile_cost = d->cost[d->sched_cur];
     d->sched_cur ^= 1;                // after this launch, cost[sched_cur ^ 1] is the buffer just written
     d->sched_key = key;
@@ -1003,21 +1231,16 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
   if (variant == 5) {
     // unit = 2 neighbouring pixels x `slab` samples, default 64 (128 paths, pixel-major: the 64 lanes of a wave sit on one
     // pixel, then on its neighbour); it is also the granularity at which waves share a tile at the end of a launch.
-    // Measured on the current kernel, helmet frame / rank 0 of 8: 32 samples 36.9 / 5.39 ms, 64 36.15 / 5.31, 128 36.6
-    // (32 was the optimum before node blocks were culled by the tile's pyramid and hits were parked).
+    // Measured, helmet frame / rank 0 of 8: 32 samples 36.9 / 5.39 ms, 64 36.15 / 5.31, 128 36.6.
     const int n_samples = K.sample_end - K.sample_first;
     int cs = p->slab > 0 ? p->slab : 64;
     int cshift = 0;
     while ((1 << cshift) < cs && (1 << cshift) < n_samples) cshift++;
     K.chunk_shift = cshift;
-    K.n_tiles = K.n_local_chunks * 16;
     K.n_sample_blocks = (n_samples + (1 << cshift) - 1) >> cshift;
     K.n_chunks_tile = 32 * K.n_sample_blocks;          // units: 8 rows x sample blocks x 4 pixel pairs
-    K.drain_thresh = K.sched_thresh;
-    if (const char *e = getenv("RT_DRAIN_THRESH")) {
-      int v = atoi(e);
-      if (v >= 1 && v <= 64) K.drain_thresh = v;
-    }
+    K.drain_thresh = knob_int("RT_DRAIN_THRESH", K.sched_thresh);
+    if (K.drain_thresh < 1 || K.drain_thresh > 64) K.drain_thresh = K.sched_thresh;
     if (d->tile_next_n < K.n_tiles) {
       (void)hipFree(d->tile_next);
       d->tile_next = nullptr;
@@ -1028,23 +1251,18 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     }
     K.tile_next = d->tile_next;
     K.open_groups = d->tile_next + d->tile_next_n;
-    {
-      int rc2 = rt_launch_stream_init(K.n_tiles, K.tile_next, K.open_groups, stream);
-      if (rc2 != 0) return rt_fail("stream init kernel failed: %s", hipGetErrorString((hipError_t)rc2));
-    }
     int64_t chunks = (int64_t)K.n_tiles * K.n_chunks_tile;
-    n_waves = g_num_cus * waves_per_cu;
+    n_waves = D.num_cus * waves_per_cu;
     if ((int64_t)n_waves > chunks) n_waves = (int)chunks;
-    // units per atomic: 1 unit of 128 paths (what a wave still holds when the launch runs dry is its tail).  Measured with
-    // units of 64 paths: helmet frame 4 -> 47.27 ms, 2 -> 47.19, 1 -> 47.45; a rank of the 8-GPU partition 4 -> 6.97 / 7.14
-    // / 6.79 ms, 2 -> 6.72 / 6.77 / 6.46, 1 -> 6.65 / 6.66 / 6.45.  With units of 128 paths: frame 1 -> 36.25, 2 -> 36.4,
-    // 4 -> 37.2; ranks 0 / 4 of 8: 5.33 / 5.63, 5.34 / 5.61, 5.86 / 6.48.  Smaller units (few samples) are taken in pairs.
+    // units per atomic: 1 unit of 128 paths (what a wave still holds when the launch runs dry is its tail); smaller
+    // units (few samples) are taken in pairs.  Measured with units of 128 paths: frame 1 -> 36.25 ms, 2 -> 36.4, 4 -> 37.2.
     K.grab_max = (cshift >= 6 || (int64_t)K.n_tiles < (int64_t)2 * n_waves) ? 1 : 2;
-    K.pyr_nodes = K.n_lds_nodes;
-    if (const char *e = getenv("RT_PYRAMID")) {
-      if (atoi(e) == 0) K.pyr_nodes = 0;
+    {
+      int v = knob_int("RT_GRAB", 0);
+      if (v == 1 || v == 2 || v == 4) K.grab_max = v;
     }
-    // Leaf blocks with the short reciprocal (rcp_exact, rt_kernels.hip): equal to the IEEE division while every triangle
+    K.pyr_nodes = knob_int("RT_PYRAMID", 1) ? K.n_lds_nodes : 0;
+    // Leaf blocks with the short reciprocal (rcp_exact, rt_dev.hip.h): equal to the IEEE division while every triangle
     // determinant |e1 . (d x e2)| <= 6 D E^2 stays below 2^102.  E = largest edge component of the scene; D = largest
     // component of a ray direction: <= 3 max|view matrix entry| for camera rays (the direction is normalised before the
     // matrix is applied), < 2 for the normalised directions that shading emits.  E <= 2^38 and matrix entries <= 2^16
@@ -1056,17 +1274,10 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
         if (!(m <= cam_max)) cam_max = m;
       }
     K.short_div = (d->max_edge <= 0x1p38f && cam_max <= 0x1p16f) ? 1 : 0;
-    if (const char *e = getenv("RT_SHORT_DIV")) {
-      if (atoi(e) == 0) K.short_div = 0;
-    }
-    if (const char *e = getenv("RT_GRAB")) {
-      int v = atoi(e);
-      if (v == 1 || v == 2 || v == 4) K.grab_max = v;
-    }
-    // hits parked until a dense shade block can be made of them: 18 x 128 dwords per wave (RT_PARK=0: shade at once)
+    if (knob_int("RT_SHORT_DIV", 1) == 0) K.short_div = 0;
+    // hits parked until a dense shade block can be made of them: 18 x 128 dwords per wave
     K.park = nullptr;
-    const char *park_env = getenv("RT_PARK");
-    if (!(park_env && atoi(park_env) == 0) && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
+    if (pipeline == 0 && knob_int("RT_PARK", 1) != 0 && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
       const int grid_waves = (n_waves + 15) / 16 * 16;         // whole workgroups of 16 waves are launched
       if (d->park_waves < grid_waves) {
         (void)hipFree(d->park);
@@ -1079,106 +1290,248 @@ static int render_accumulate_locked(RT_Device_Scene *d, Camera const *cam, RT_Re
     }
   }
 
+  // ---- ONE preparation launch: counters, work head, tile / unit counters, this launch's cost buffer, tile order ----
+  {
+    int rc2 = rt_launch_prepare(K.n_tiles, variant == 5 ? K.tile_next : nullptr, variant == 5 ? K.open_groups : nullptr, d->counters,
+                                d->work_head, K.tile_cost, cost_prev, cost_prev ? d->order : nullptr, stream);
+    if (rc2 != 0) return rt_fail("prepare kernel launch failed: %s", hipGetErrorString((hipError_t)rc2));
+  }
+  if (ev_prep) HIP_TRY(hipEventRecord(ev_prep, stream));
+  if (K.n_work == 0) return 0;
+
   K.wave_times = nullptr;
-  if (variant == 4 || (variant == 5 && getenv("RT_WAVE_TIMES"))) {      // wave timeline (tools/exp_waves.py)
-    if (!g_ws.wave_times) HIP_TRY(hipMalloc(&g_ws.wave_times, (size_t)65536 * 3 * 8));
-    HIP_TRY(hipMemsetAsync(g_ws.wave_times, 0, (size_t)65536 * 3 * 8, stream));
-    K.wave_times = g_ws.wave_times;
+  if (variant == 4 || (variant == 5 && knob_set("RT_WAVE_TIMES"))) {      // wave timeline (tools/exp_waves.py)
+    if (!D.ws.wave_times) HIP_TRY(hipMalloc(&D.ws.wave_times, (size_t)65536 * 3 * 8));
+    HIP_TRY(hipMemsetAsync(D.ws.wave_times, 0, (size_t)65536 * 3 * 8, stream));
+    K.wave_times = D.ws.wave_times;
     if (n_waves > 65536) n_waves = 65536;          // the diagnostic buffer holds that many waves
-    g_ws.wave_times_n = n_waves;
+    D.ws.wave_times_n = n_waves;
   }
 
-  size_t slot = g_ws.n_timed % RT_MAX_TIMED;
-  if (slot >= g_ws.ev0.size()) {
+  size_t slot = D.ws.n_timed % RT_MAX_TIMED;
+  if (slot >= D.ws.ev0.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
-    g_ws.ev0.push_back(a);
-    g_ws.ev1.push_back(b);
+    D.ws.ev0.push_back(a);
+    D.ws.ev1.push_back(b);
   }
-  HIP_TRY(hipEventRecord(g_ws.ev0[slot], stream));
-  const char *pipe = getenv("RT_PIPELINE");
-  if (variant == 5 && pipe && strcmp(pipe, "wf") == 0) {
-    if (launch_wavefront(d, K, stream) != 0) return -1;
+  HIP_TRY(hipEventRecord(D.ws.ev0[slot], stream));
+  if (pipeline == 1) {
+    if (launch_wavefront(D, d, K, stream) != 0) return -1;
   } else {
     int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, stream);
     if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   }
-  HIP_TRY(hipEventRecord(g_ws.ev1[slot], stream));
-  g_ws.n_timed += 1;
+  HIP_TRY(hipEventRecord(D.ws.ev1[slot], stream));
+  D.ws.n_timed += 1;
   return 0;
 }
 
 extern "C" int rt_set_camera(RT_Device_Scene *dscene, Camera const *camera) {
-  std::lock_guard<std::mutex> lock(g_mutex);
   if (!dscene || !camera) return rt_fail("rt_set_camera: NULL argument");
-  g_cameras[dscene] = *camera;
+  Device &D = *dscene->dev;
+  std::lock_guard<std::mutex> lock(D.mutex);
+  D.cameras[dscene] = *camera;
   return 0;
 }
 
 extern "C" int rt_render_accumulate(RT_Device_Scene *dscene, RT_Render_Params const *params, void *d_accum,
                                     void *stream) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  auto it = g_cameras.find(dscene);
-  if (it == g_cameras.end()) return rt_fail("rt_render_accumulate: no camera set for this scene (rt_set_camera)");
-  return render_accumulate_locked(dscene, &it->second, params, d_accum, (hipStream_t)stream);
+  if (!dscene) return rt_fail("rt_render_accumulate: NULL scene or accumulation buffer");
+  Device &D = *dscene->dev;
+  std::lock_guard<std::mutex> lock(D.mutex);
+  DeviceGuard guard(D);
+  auto it = D.cameras.find(dscene);
+  if (it == D.cameras.end()) return rt_fail("rt_render_accumulate: no camera set for this scene (rt_set_camera)");
+  return render_accumulate_locked(D, dscene, &it->second, params, d_accum, (hipStream_t)stream);
 }
 
-extern "C" int rt_resolve(RT_Render_Params const *p, void const *d_accum, void *d_tiles, void *d_image,
-                          void *d_linear, void *stream) {
-  if (ensure_device() != 0) return -1;
+static int resolve_on(Device &D, RT_Render_Params const *p, void const *d_accum, void *d_tiles, void *d_image, void *d_linear,
+                      hipStream_t stream) {
   if (check_params(p) != 0) return -1;
   if (!d_accum) return rt_fail("rt_resolve: NULL accumulation buffer");
   int chunks_x = (p->width + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE;
   const int32_t *d_list = nullptr;
   int n_local = 0;
-  if (device_chunk_list(p->width, p->height, p->rank, p->world, &d_list, &n_local) != 0) return -1;
+  if (device_chunk_list(D, p->width, p->height, p->rank, p->world, &d_list, &n_local) != 0) return -1;
   int rc = rt_launch_resolve(p->width, p->height, p->samples, chunks_x, d_list, n_local,
                              (const unsigned long long *)d_accum, (uint8_t *)d_tiles, (uint8_t *)d_image,
-                             (float *)d_linear, (hipStream_t)stream);
+                             (float *)d_linear, stream);
   if (rc != 0) return rt_fail("resolve kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 
-extern "C" int rt_untile(i32 width, i32 height, i32 world, void const *d_all_tiles, void *d_image, void *stream) {
-  if (ensure_device() != 0) return -1;
+extern "C" int rt_resolve(RT_Render_Params const *p, void const *d_accum, void *d_tiles, void *d_image,
+                          void *d_linear, void *stream) {
+  Device &D = dev0();
+  {
+    std::lock_guard<std::mutex> lock(D.mutex);
+    if (ensure_device(D) != 0) return -1;
+  }
+  return resolve_on(D, p, d_accum, d_tiles, d_image, d_linear, (hipStream_t)stream);
+}
+
+static int untile_on(Device &D, i32 width, i32 height, i32 world, void const *d_all_tiles, void *d_image, hipStream_t stream) {
   if (width <= 0 || height <= 0 || world <= 0 || !d_all_tiles || !d_image) return rt_fail("rt_untile: bad arguments");
   int chunks_x = (width + RT_CHUNK_SIZE - 1) / RT_CHUNK_SIZE;
   const int32_t *d_table = nullptr;
   int n_chunks = 0;
   if (!partition_args_ok(width, height, world)) return rt_fail("rt_untile: bad arguments");
-  if (device_owner_table(width, height, world, &d_table, &n_chunks) != 0) return -1;
+  if (device_owner_table(D, width, height, world, &d_table, &n_chunks) != 0) return -1;
   int rc = rt_launch_untile(width, height, chunks_x, n_chunks, d_table, (const uint8_t *)d_all_tiles,
-                            (uint8_t *)d_image, (hipStream_t)stream);
+                            (uint8_t *)d_image, stream);
   if (rc != 0) return rt_fail("untile kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 
-static int ensure_frame_buffers(int width, int height) {
+extern "C" int rt_untile(i32 width, i32 height, i32 world, void const *d_all_tiles, void *d_image, void *stream) {
+  Device &D = dev0();
+  {
+    std::lock_guard<std::mutex> lock(D.mutex);
+    if (ensure_device(D) != 0) return -1;
+  }
+  return untile_on(D, width, height, world, d_all_tiles, d_image, (hipStream_t)stream);
+}
+
+static int ensure_frame_buffers(Device &D, int width, int height, size_t tiles_bytes, size_t all_tiles_bytes) {
+  Workspace &W = D.ws;
   size_t pixels = (size_t)width * height;
-  if (g_ws.accum_elems < pixels * 3) {
-    (void)hipFree(g_ws.accum);
-    g_ws.accum = nullptr;
-    g_ws.accum_elems = 0;
-    HIP_TRY(hipMalloc(&g_ws.accum, pixels * 3 * sizeof(unsigned long long)));
-    g_ws.accum_elems = pixels * 3;
+  if (W.accum_elems < pixels * 3) {
+    (void)hipFree(W.accum);
+    W.accum = nullptr;
+    W.accum_elems = 0;
+    HIP_TRY(hipMalloc(&W.accum, pixels * 3 * sizeof(unsigned long long)));
+    W.accum_elems = pixels * 3;
   }
-  if (g_ws.image_pixels < pixels) {
-    (void)hipFree(g_ws.image);
-    (void)hipFree(g_ws.linear);
-    g_ws.image = nullptr;
-    g_ws.linear = nullptr;
-    g_ws.image_pixels = 0;
-    HIP_TRY(hipMalloc(&g_ws.image, pixels * 3));
-    HIP_TRY(hipMalloc(&g_ws.linear, pixels * 3 * sizeof(float)));
-    g_ws.image_pixels = pixels;
+  if (W.image_pixels < pixels) {
+    (void)hipFree(W.image);
+    (void)hipFree(W.linear);
+    W.image = nullptr;
+    W.linear = nullptr;
+    W.image_pixels = 0;
+    HIP_TRY(hipMalloc(&W.image, pixels * 3));
+    HIP_TRY(hipMalloc(&W.linear, pixels * 3 * sizeof(float)));
+    W.image_pixels = pixels;
   }
+  if (W.tiles_bytes < tiles_bytes) {
+    (void)hipFree(W.tiles);
+    W.tiles = nullptr;
+    W.tiles_bytes = 0;
+    HIP_TRY(hipMalloc(&W.tiles, tiles_bytes));
+    W.tiles_bytes = tiles_bytes;
+  }
+  if (W.all_tiles_bytes < all_tiles_bytes) {
+    (void)hipFree(W.all_tiles);
+    W.all_tiles = nullptr;
+    W.all_tiles_bytes = 0;
+    HIP_TRY(hipMalloc(&W.all_tiles, all_tiles_bytes));
+    W.all_tiles_bytes = all_tiles_bytes;
+  }
+  for (int i = 0; i < 5; i++)
+    if (!W.ev_frame[i]) HIP_TRY(hipEventCreate(&W.ev_frame[i]));
+  return 0;
+}
+
+static int copy_image_out(Image const *image, const uint8_t *d_image, int width, int height, hipStream_t stream) {
+  size_t pixels = (size_t)width * height;
+  if (!image->pixels.data) return 0;
+  if (image->components == 3 && image->stride == image->width) {
+    HIP_TRY(hipMemcpyAsync(image->pixels.data, d_image, pixels * 3, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  } else {
+    std::vector<uint8_t> tmp(pixels * 3);
+    HIP_TRY(hipMemcpy(tmp.data(), d_image, pixels * 3, hipMemcpyDeviceToHost));
+    for (isize y = 0; y < image->height; y++)
+      for (isize x = 0; x < image->width; x++)
+        for (int c = 0; c < 3; c++)
+          image->pixels.data[image->components * (x + y * image->stride) + c] = tmp[((size_t)y * width + x) * 3 + c];
+  }
+  return 0;
+}
+
+static float event_ms(hipEvent_t a, hipEvent_t b) {
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+// ---- a frame spread over the N GPUs of this node, behind the reference's own entry points ------------------------------
+// driver.c:793-803 starts `-T n` threads on render_thread_proc; the one that claims the frame drives N devices (N =
+// rt_device_count()): every device holds its own copy of the scene, renders the chunks rt_chunk_owner() gives its rank and
+// resolves them to compact u8 tiles; the tiles travel to device 0 with ONE peer copy per device over xGMI
+// (hipMemcpyPeerAsync; 0.78 MB each at 1080p), device 0 untiles into the row-major image and copies it to the caller's
+// pixels.  Devices are driven by one internal host thread each (uploads and launches proceed in parallel; the calling
+// application's other threads return at once, as in the one-GPU case).  Per-path seeds depend on (pixel, sample) only, so
+// the image does not depend on N (tests/test_gpu_multi_device.py: byte-equal to the one-device frame).
+static int render_frame_multi(Scene const *scene, Image const *image, RT_Render_Params base, int world) {
+  Device &D0 = dev0();                               // D0.mutex held by the caller
+  const int w = base.width, h = base.height;
+  const size_t max_local = (size_t)rt_max_local_chunk_count(w, h, world);
+  const size_t tiles_bytes = max_local * 1024 * 3;
+  if (ensure_frame_buffers(D0, w, h, tiles_bytes, tiles_bytes * (size_t)world) != 0) return -1;
+  const double t0 = now_ms();
+  std::vector<int> rcs((size_t)world, 0);
+  std::vector<RT_Counters> cnts((size_t)world);
+  auto work = [&](int r) {
+    Device &D = g_devs[r];
+    std::unique_lock<std::mutex> lock(D.mutex, std::defer_lock);
+    if (r != 0) lock.lock();
+    D.slot = r;
+    DeviceGuard guard(D);
+    rcs[(size_t)r] = -1;
+    if (ensure_device(D) != 0) return;
+    RT_Device_Scene *d = cached_scene_locked(D, scene, nullptr, nullptr);
+    if (!d) return;
+    if (ensure_frame_buffers(D, w, h, tiles_bytes, r == 0 ? tiles_bytes * (size_t)world : 0) != 0) return;
+    RT_Render_Params p = base;
+    p.rank = r;
+    p.world = world;
+    hipStream_t stream = nullptr;
+    if (hipMemsetAsync(D.ws.accum, 0, (size_t)w * h * 3 * sizeof(unsigned long long), stream) != hipSuccess) { rt_fail("hipMemsetAsync failed"); return; }
+    if (render_accumulate_locked(D, d, &scene->camera, &p, D.ws.accum, stream) != 0) return;
+    if (resolve_on(D, &p, D.ws.accum, D.ws.tiles, nullptr, nullptr, stream) != 0) return;
+    uint8_t *dst = D0.ws.all_tiles + (size_t)r * tiles_bytes;
+    hipError_t e = (D.phys == D0.phys) ? hipMemcpyAsync(dst, D.ws.tiles, tiles_bytes, hipMemcpyDeviceToDevice, stream)
+                                       : hipMemcpyPeerAsync(dst, D0.phys, D.ws.tiles, D.phys, tiles_bytes, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { rt_fail("tile copy from device %d failed: %s", D.phys, hipGetErrorString(e)); return; }
+    unsigned long long c[RT_N_COUNTERS];
+    if (hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { rt_fail("counter read-back failed"); return; }
+    RT_Counters &o = cnts[(size_t)r];
+    o.paths = c[0]; o.rays = c[1]; o.node_visits = c[2]; o.leaf_visits = c[3]; o.shades = c[4]; o.backgrounds = c[5]; o.textured = c[6];
+    rcs[(size_t)r] = 0;
+  };
+  std::vector<std::thread> helpers;
+  for (int r = 1; r < world; r++) helpers.emplace_back(work, r);
+  work(0);
+  for (auto &t : helpers) t.join();
+  for (int r = 0; r < world; r++)
+    if (rcs[(size_t)r] != 0) return -1;
+  DeviceGuard guard(D0);
+  if (untile_on(D0, w, h, world, D0.ws.all_tiles, D0.ws.image, nullptr) != 0) return -1;
+  if (copy_image_out(image, D0.ws.image, w, h, nullptr) != 0) return -1;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  {
+    std::lock_guard<std::mutex> lk(g_multi_mutex);
+    memset(&g_multi_counters, 0, sizeof g_multi_counters);
+    for (const RT_Counters &o : cnts) {
+      g_multi_counters.paths += o.paths; g_multi_counters.rays += o.rays; g_multi_counters.node_visits += o.node_visits;
+      g_multi_counters.leaf_visits += o.leaf_visits; g_multi_counters.shades += o.shades; g_multi_counters.backgrounds += o.backgrounds;
+      g_multi_counters.textured += o.textured;
+    }
+    g_multi_counters_valid = true;
+  }
+  D0.timing = FrameTiming();
+  D0.timing.total_ms = (float)(now_ms() - t0);
   return 0;
 }
 
 static int render_frame_locked(Scene const *scene, Image const *image, isize samples, isize max_bounces,
                                f32 *linear, u64 *accum) {
-  if (ensure_device() != 0) return -1;
+  Device &D = dev0();
+  const double t_start = now_ms();
+  if (ensure_device(D) != 0) return -1;
   if (!scene || !image) return rt_fail("render: NULL scene or image");
   if (image->pixels.data && image->components < 3) return rt_fail("render: image needs >= 3 components");
   if (image->pixels.data && image->stride < image->width) return rt_fail("render: image stride < width");
@@ -1188,54 +1541,89 @@ static int render_frame_locked(Scene const *scene, Image const *image, isize sam
   p.height = (i32)image->height;
   p.samples = (i32)samples;
   p.max_bounces = (i32)max_bounces;
-  p.seed = g_seed;
+  p.seed = g_seed.load();
   p.rank = 0;
   p.world = 1;
   if (check_params(&p) != 0) return -1;
-  RT_Device_Scene *d = cached_scene_locked(scene);
+  {
+    std::lock_guard<std::mutex> lk(g_multi_mutex);
+    g_multi_counters_valid = false;
+  }
+  const int world = rt_device_count();
+  if (world > 1 && !linear && !accum && rt_chunk_count(p.width, p.height) >= world)
+    return render_frame_multi(scene, image, p, world);
+
+  FrameTiming T;
+  RT_Device_Scene *d = cached_scene_locked(D, scene, &T.stamp_ms, &T.upload_ms);
   if (!d) return -1;
-  if (ensure_frame_buffers(p.width, p.height) != 0) return -1;
+  if (ensure_frame_buffers(D, p.width, p.height, 0, 0) != 0) return -1;
+  Workspace &W = D.ws;
 
   size_t pixels = (size_t)p.width * p.height;
   hipStream_t stream = nullptr;
-  HIP_TRY(hipMemsetAsync(g_ws.accum, 0, pixels * 3 * sizeof(unsigned long long), stream));
-  if (render_accumulate_locked(d, &scene->camera, &p, g_ws.accum, stream) != 0) return -1;
-  if (rt_resolve(&p, g_ws.accum, nullptr, g_ws.image, linear ? g_ws.linear : nullptr, stream) != 0) return -1;
+  const double t_enq = now_ms();
+  HIP_TRY(hipEventRecord(W.ev_frame[0], stream));
+  HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 3 * sizeof(unsigned long long), stream));
+  if (render_accumulate_locked(D, d, &scene->camera, &p, W.accum, stream, W.ev_frame[1]) != 0) return -1;
+  HIP_TRY(hipEventRecord(W.ev_frame[2], stream));
+  if (resolve_on(D, &p, W.accum, nullptr, W.image, linear ? W.linear : nullptr, stream) != 0) return -1;
+  HIP_TRY(hipEventRecord(W.ev_frame[3], stream));
+  T.enqueue_ms = (float)(now_ms() - t_enq);
 
-  if (image->pixels.data) {
-    if (image->components == 3 && image->stride == image->width) {
-      HIP_TRY(hipMemcpyAsync(image->pixels.data, g_ws.image, pixels * 3, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-    } else {
-      std::vector<uint8_t> tmp(pixels * 3);
-      HIP_TRY(hipMemcpy(tmp.data(), g_ws.image, pixels * 3, hipMemcpyDeviceToHost));
-      for (isize y = 0; y < image->height; y++)
-        for (isize x = 0; x < image->width; x++)
-          for (int c = 0; c < 3; c++)
-            image->pixels.data[image->components * (x + y * image->stride) + c] = tmp[((size_t)y * p.width + x) * 3 + c];
-    }
-  }
-  if (linear) HIP_TRY(hipMemcpy(linear, g_ws.linear, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
-  if (accum) HIP_TRY(hipMemcpy(accum, g_ws.accum, pixels * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (copy_image_out(image, W.image, p.width, p.height, stream) != 0) return -1;
+  HIP_TRY(hipEventRecord(W.ev_frame[4], stream));
+  if (linear) HIP_TRY(hipMemcpy(linear, W.linear, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (accum) HIP_TRY(hipMemcpy(accum, W.accum, pixels * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipGetLastError());
+  T.gpu_prep_ms = event_ms(W.ev_frame[0], W.ev_frame[1]);
+  T.gpu_path_ms = event_ms(W.ev_frame[1], W.ev_frame[2]);
+  T.gpu_resolve_ms = event_ms(W.ev_frame[2], W.ev_frame[3]);
+  T.gpu_copy_ms = event_ms(W.ev_frame[3], W.ev_frame[4]);
+  T.total_ms = (float)(now_ms() - t_start);
+  D.timing = T;
   return 0;
 }
 
 extern "C" int rt_render_frame(Scene const *scene, Image const *image, isize samples, isize max_bounces, f32 *linear,
                                u64 *accum) {
-  std::lock_guard<std::mutex> lock(g_mutex);
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
   return render_frame_locked(scene, image, samples, max_bounces, linear, accum);
 }
 
-extern "C" int rt_get_counters(RT_Counters *out) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (!out) return rt_fail("rt_get_counters: NULL");
-  if (ensure_device() != 0) return -1;
-  unsigned long long c[RT_N_COUNTERS];
+// Where the time of the last frame behind render_thread_proc / render / rt_render_frame went (one-device frames; a
+// multi-device frame reports total_ms only).  Host: stamp = the per-frame scene check, upload = scene upload when it
+// happened, enqueue = launching the frame; GPU (HIP events on the frame's stream): prep = accumulator clear + the
+// preparation kernel, path = the path kernel, resolve, copy = device-to-host copy of the image; total = wall clock of the call.
+extern "C" int rt_get_frame_timing(RT_Frame_Timing *out) {
+  if (!out) return rt_fail("rt_get_frame_timing: NULL");
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  out->stamp_ms = D.timing.stamp_ms; out->upload_ms = D.timing.upload_ms; out->enqueue_ms = D.timing.enqueue_ms;
+  out->gpu_prep_ms = D.timing.gpu_prep_ms; out->gpu_path_ms = D.timing.gpu_path_ms; out->gpu_resolve_ms = D.timing.gpu_resolve_ms;
+  out->gpu_copy_ms = D.timing.gpu_copy_ms; out->total_ms = D.timing.total_ms;
+  return 0;
+}
+
+static int read_counters(Device &D, unsigned long long c[RT_N_COUNTERS]) {
   HIP_TRY(hipDeviceSynchronize());
-  if (!g_last_counters) { memset(c, 0, sizeof c); } else
-  HIP_TRY(hipMemcpy(c, g_last_counters, sizeof c, hipMemcpyDeviceToHost));
+  if (!D.last_counters) { memset(c, 0, RT_N_COUNTERS * sizeof(unsigned long long)); return 0; }
+  HIP_TRY(hipMemcpy(c, D.last_counters, RT_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int rt_get_counters(RT_Counters *out) {
+  if (!out) return rt_fail("rt_get_counters: NULL");
+  {
+    std::lock_guard<std::mutex> lk(g_multi_mutex);
+    if (g_multi_counters_valid) { *out = g_multi_counters; return 0; }
+  }
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0) return -1;
+  unsigned long long c[RT_N_COUNTERS];
+  if (read_counters(D, c) != 0) return -1;
   out->paths = c[0];
   out->rays = c[1];
   out->node_visits = c[2];
@@ -1246,55 +1634,58 @@ extern "C" int rt_get_counters(RT_Counters *out) {
   return 0;
 }
 
-static float timed_slot_ms(size_t slot) {
-  if (hipEventSynchronize(g_ws.ev1[slot]) != hipSuccess) return -1.0f;
-  float ms = -1.0f;
-  if (hipEventElapsedTime(&ms, g_ws.ev0[slot], g_ws.ev1[slot]) != hipSuccess) return -1.0f;
-  return ms;
+static float timed_slot_ms(Workspace &W, size_t slot) {
+  if (hipEventSynchronize(W.ev1[slot]) != hipSuccess) return -1.0f;
+  return event_ms(W.ev0[slot], W.ev1[slot]);
 }
 
 // Block statistics of the diagnostic kernel (RT_KERNEL=4): 8 pairs (executions, lanes) for
 // shade, environment, regenerate, leaf-scalar, leaf-vector, node-scalar, node-vector, pop.
 extern "C" int rt_get_sched_stats(u64 out[32]) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0 || !out) return -1;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0 || !out) return -1;
   unsigned long long c[RT_N_COUNTERS];
-  HIP_TRY(hipDeviceSynchronize());
-  if (!g_last_counters) { memset(c, 0, sizeof c); } else
-  HIP_TRY(hipMemcpy(c, g_last_counters, sizeof c, hipMemcpyDeviceToHost));
+  if (read_counters(D, c) != 0) return -1;
   for (int i = 0; i < 32; i++) out[i] = c[8 + i];
   return 0;
 }
 
 // Diagnostic kernel (RT_KERNEL=4): per wave start time, end time (100 MHz ticks) and items processed.
 extern "C" int rt_get_wave_times(u64 *out, i32 max_waves) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0 || !out || !g_ws.wave_times) return -1;
-  int n = g_ws.wave_times_n < max_waves ? g_ws.wave_times_n : max_waves;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0 || !out || !D.ws.wave_times) return -1;
+  int n = D.ws.wave_times_n < max_waves ? D.ws.wave_times_n : max_waves;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, g_ws.wave_times, (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, D.ws.wave_times, (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
   return n;
 }
 
 extern "C" f32 rt_last_kernel_ms(void) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (!g_device_ready || g_ws.n_timed == 0) return -1.0f;
-  return timed_slot_ms((g_ws.n_timed - 1) % RT_MAX_TIMED);
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (!D.ready || D.ws.n_timed == 0) return -1.0f;
+  DeviceGuard guard(D);
+  return timed_slot_ms(D.ws, (D.ws.n_timed - 1) % RT_MAX_TIMED);
 }
 
 extern "C" void rt_kernel_timing_reset(void) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  g_ws.n_timed = 0;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  D.ws.n_timed = 0;
 }
 
 extern "C" f32 rt_kernel_timing_mean_ms(i32 *n_launches) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  size_t n = g_ws.n_timed < RT_MAX_TIMED ? g_ws.n_timed : RT_MAX_TIMED;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  size_t n = D.ws.n_timed < RT_MAX_TIMED ? D.ws.n_timed : RT_MAX_TIMED;
   if (n_launches) *n_launches = (i32)n;
-  if (!g_device_ready || n == 0) return -1.0f;
+  if (!D.ready || n == 0) return -1.0f;
+  DeviceGuard guard(D);
   double sum = 0.0;
   for (size_t i = 0; i < n; i++) {
-    float ms = timed_slot_ms(i);
+    float ms = timed_slot_ms(D.ws, i);
     if (ms < 0.0f) return -1.0f;
     sum += ms;
   }
@@ -1308,10 +1699,11 @@ extern "C" void render_thread_proc(Rendering_Context *ctx) {
   if (!ctx) return;
   i32 c = __atomic_fetch_add(&ctx->_current_chunk, 1, __ATOMIC_SEQ_CST);
   if (c == 0) {
-    // this entrant owns the frame
+    // this entrant owns the frame (all rt_device_count() GPUs of it: render_frame_multi)
     int rc;
     {
-      std::lock_guard<std::mutex> lock(g_mutex);
+      Device &D = dev0();
+      std::lock_guard<std::mutex> lock(D.mutex);
       rc = render_frame_locked(ctx->scene, &ctx->image, ctx->samples, ctx->max_bounces, nullptr, nullptr);
     }
     (void)rc;   // failure text is in rt_last_error(); the context still completes
@@ -1331,18 +1723,18 @@ extern "C" void rendering_context_finish(Rendering_Context *context) {
 
 // raytracer.c:722-784 on the GPU; semantics and the three documented choices
 // (last triangle wins, texels outside the image skipped, per-texel seeding) are in oracle/oracle.h.
-static int lightmap_bake_locked(Image const *lightmap, Scene const *scene, isize samples) {
-  if (ensure_device() != 0) return -1;
+static int lightmap_bake_locked(Device &D, Image const *lightmap, Scene const *scene, isize samples) {
+  if (ensure_device(D) != 0) return -1;
   if (!lightmap || !scene || !lightmap->pixels.data) return rt_fail("lightmap_bake: NULL argument");
   if (lightmap->pixel_type != PT_u8 || lightmap->components < 3) return rt_fail("lightmap_bake: need a u8 image with >= 3 components");
   if (samples <= 0 || lightmap->width <= 0 || lightmap->height <= 0 || lightmap->stride < lightmap->width)
     return rt_fail("lightmap_bake: bad size or sample count");
-  RT_Device_Scene *d = cached_scene_locked(scene);
+  RT_Device_Scene *d = cached_scene_locked(D, scene, nullptr, nullptr);
   if (!d) return -1;
   RT_KParams K;
   scene_only_kparams(&K, d);
   K.max_bounces = 8;            // cast_ray(scene, r, 8), raytracer.c:774
-  K.seed = g_seed;
+  K.seed = g_seed.load();
   const Triangles &T = scene->triangles;
   std::vector<float> verts((size_t)T.len * 9);
   for (int i = 0; i < T.len; i++)
@@ -1371,8 +1763,9 @@ static int lightmap_bake_locked(Image const *lightmap, Scene const *scene, isize
 }
 
 extern "C" void lightmap_bake(Image const *lightmap, Scene const *scene, isize samples) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  lightmap_bake_locked(lightmap, scene, samples);
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  lightmap_bake_locked(D, lightmap, scene, samples);
 }
 
 extern "C" int render(Scene *scene, Image *image, isize samples, isize max_bounces) {
@@ -1387,15 +1780,17 @@ extern "C" int rt_gpu_build(const Triangle *h_tris, long n_in, long depth, BVH_N
 
 extern "C" int scene_init_gpu(Scene *scene, Triangle_Slice src, Allocator allocator) {
   if (!scene) return rt_fail("scene_init_gpu: scene is NULL");
+  Device &D = dev0();
   {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (ensure_device() != 0) return -1;
+    std::lock_guard<std::mutex> lock(D.mutex);
+    if (ensure_device(D) != 0) return -1;
   }
   if (src.len < 0 || (src.len > 0 && !src.data)) return rt_fail("scene_init_gpu: bad triangle slice");
   if (src.len > (isize)1 << 27) return rt_fail("scene_init_gpu: %ld triangles are too many", (long)src.len);
   if (!rt_scene_alloc(scene, src.len, allocator)) return rt_fail("scene_init_gpu: the allocator failed");   // (drops a stale device copy)
   char err[256] = "";
-  std::lock_guard<std::mutex> lock(g_mutex);
+  std::lock_guard<std::mutex> lock(D.mutex);
+  DeviceGuard guard(D);
   int rc = rt_gpu_build(src.data, (long)src.len, (long)scene->bvh.depth, scene->bvh.nodes.data, (long)scene->bvh.nodes.len,
                         scene->triangles.x[0], (long)scene->triangles.len, err, (int)sizeof err);
   if (rc != 0) return rt_fail("scene_init_gpu: %s", err);
@@ -1406,7 +1801,11 @@ extern "C" int scene_init_gpu(Scene *scene, Triangle_Slice src, Allocator alloca
 // denoiser (reference denoiser.h / denoiser.c:131-153), SURVEY.md section 8f #3
 
 extern "C" int rt_denoise(i32 width, i32 height, void const *d_src, void *d_dst, void *stream) {
-  if (ensure_device() != 0) return -1;
+  {
+    Device &D = dev0();
+    std::lock_guard<std::mutex> lock(D.mutex);
+    if (ensure_device(D) != 0) return -1;
+  }
   if (width <= 0 || height <= 0 || !d_src || !d_dst || d_src == d_dst) return rt_fail("rt_denoise: bad arguments");
   int rc = rt_launch_denoise(width, height, width, 3, width, 3, (const uint8_t *)d_src, (uint8_t *)d_dst, (hipStream_t)stream);
   if (rc != 0) return rt_fail("denoise kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1414,8 +1813,9 @@ extern "C" int rt_denoise(i32 width, i32 height, void const *d_src, void *d_dst,
 }
 
 static int denoise_host(Image const *src, Image const *dst) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0) return -1;
   if (!src || !dst || !src->pixels.data || !dst->pixels.data) return rt_fail("denoise_image: NULL image");
   if (src->pixels.data == dst->pixels.data) return rt_fail("denoise_image: src and dst must differ (denoiser.c:134)");
   if (src->width != dst->width || src->height != dst->height) return rt_fail("denoise_image: size mismatch");
@@ -1441,12 +1841,14 @@ extern "C" void denoise_image(Image const *src, Image const *dst, isize n_thread
   denoise_host(src, dst);
 }
 
+
 // ---------------------------------------------------------------------------------
 // unit-level device entry points
 
 extern "C" int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0) return -1;
   if (n <= 0 || !x || !out) return rt_fail("rt_test_math: bad arguments");
   DevBuf bx, by, bout;
   size_t bytes = (size_t)n * sizeof(float);
@@ -1465,52 +1867,33 @@ extern "C" int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out)
   return 0;
 }
 
-// rcp_exact() (the four-instruction reciprocal of the leaf blocks) against the IEEE quotient over all 2^32 bit patterns:
-// out[0] differing patterns inside its domain (must be 0), out[1] patterns outside the domain, out[2] differing ones
-// among those, out[3] first differing pattern inside the domain + 1.
-extern "C" int rt_test_rcp_sweep(u64 out[4]) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
-  if (!out) return rt_fail("rt_test_rcp_sweep: NULL");
+static int run_sweep(int (*launch)(unsigned long long *, hipStream_t), const char *name, u64 *out, int n_out) {
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0) return -1;
+  if (!out) return rt_fail("%s: NULL", name);
   DevBuf b;
-  HIP_TRY(b.alloc(4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(b.p, 0, 4 * sizeof(unsigned long long)));
-  int rc = rt_launch_test_rcp_sweep(b.as<unsigned long long>(), nullptr);
-  if (rc == 0) rc = (int)hipMemcpy(out, b.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  if (rc != 0) return rt_fail("rt_test_rcp_sweep failed: %s", hipGetErrorString((hipError_t)rc));
+  HIP_TRY(b.alloc((size_t)n_out * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(b.p, 0, (size_t)n_out * sizeof(unsigned long long)));
+  int rc = launch(b.as<unsigned long long>(), nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out, b.p, (size_t)n_out * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (rc != 0) return rt_fail("%s failed: %s", name, hipGetErrorString((hipError_t)rc));
   return 0;
 }
+
+// rcp_exact() (the six-instruction reciprocal of the leaf blocks) against the IEEE quotient over all 2^32 bit patterns:
+// out[0] differing patterns inside its domain (must be 0), out[1] patterns outside the domain, out[2] differing ones
+// among those, out[3] first differing pattern inside the domain + 1.
+extern "C" int rt_test_rcp_sweep(u64 out[4]) { return run_sweep(rt_launch_test_rcp_sweep, "rt_test_rcp_sweep", out, 4); }
 
 // The kernels' sRGB decode of a texture sample (division by 1.055 as a corrected multiplication) against
 // rt_srgb_to_linear1() for every float in [0, 2] (and 4 M negative ones): out[0] patterns compared, out[1] differing (0 expected),
 // out[2] first differing pattern + 1.
-extern "C" int rt_test_srgb_sweep(u64 out[3]) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
-  if (!out) return rt_fail("rt_test_srgb_sweep: NULL");
-  DevBuf b;
-  HIP_TRY(b.alloc(3 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(b.p, 0, 3 * sizeof(unsigned long long)));
-  int rc = rt_launch_test_srgb_sweep(b.as<unsigned long long>(), nullptr);
-  if (rc == 0) rc = (int)hipMemcpy(out, b.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  if (rc != 0) return rt_fail("rt_test_srgb_sweep failed: %s", hipGetErrorString((hipError_t)rc));
-  return 0;
-}
+extern "C" int rt_test_srgb_sweep(u64 out[3]) { return run_sweep(rt_launch_test_srgb_sweep, "rt_test_srgb_sweep", out, 3); }
 
 // The tile-stream kernel's shift-based fixed-point conversion of a sample against rt_accum_quantize() over all 2^32 bit
 // patterns: out[0] differing patterns (0 expected), out[1] first differing pattern + 1.
-extern "C" int rt_test_quantize_sweep(u64 out[2]) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
-  if (!out) return rt_fail("rt_test_quantize_sweep: NULL");
-  DevBuf b;
-  HIP_TRY(b.alloc(2 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(b.p, 0, 2 * sizeof(unsigned long long)));
-  int rc = rt_launch_test_quantize_sweep(b.as<unsigned long long>(), nullptr);
-  if (rc == 0) rc = (int)hipMemcpy(out, b.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  if (rc != 0) return rt_fail("rt_test_quantize_sweep failed: %s", hipGetErrorString((hipError_t)rc));
-  return 0;
-}
+extern "C" int rt_test_quantize_sweep(u64 out[2]) { return run_sweep(rt_launch_test_quantize_sweep, "rt_test_quantize_sweep", out, 2); }
 
 static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
   memset(K, 0, sizeof *K);
@@ -1527,9 +1910,11 @@ static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
 }
 
 extern "C" int rt_test_trace(RT_Device_Scene *d, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
   if (!d || n <= 0 || !rays || !out_t || !out_tri || !out_uv) return rt_fail("rt_test_trace: bad arguments");
+  Device &D = *d->dev;
+  std::lock_guard<std::mutex> lock(D.mutex);
+  DeviceGuard guard(D);
+  if (ensure_device(D) != 0) return -1;
   RT_KParams K;
   scene_only_kparams(&K, d);
   DevBuf br, bt, btri, buv;
@@ -1548,10 +1933,67 @@ extern "C" int rt_test_trace(RT_Device_Scene *d, i32 n, f32 const *rays, f32 *ou
   return 0;
 }
 
+// n rays through traversal_blocks() -- the NODE / LEAF / pop code of the path kernels -- in the path kernel's launch geometry.
+//   pyramid: NULL, or 19 floats (4 outward plane normals at [4 q .. 4 q + 2], the rays' common origin at [16 .. 18]): every
+//            ray is then treated as a camera ray of one tile and node blocks take the pyramid-culled form where the path
+//            kernel would; the caller guarantees that every ray starts at that origin and lies inside the four planes
+//   exit_lanes: 1 .. 64, how many finished lanes end a round of blocks (the path kernel's `sched_thresh`, 48)
+//   mode: 0 = the instance the path kernel would choose for this scene, 1 = force the IEEE division in the leaf blocks,
+//         2 = nodes from L1 / L2 instead of the LDS copy
+//   visits: [0] += ray_aabbs_hit_8 equivalents, [1] += ray_triangles_hit_8 equivalents
+extern "C" int rt_test_trace_stream(RT_Device_Scene *d, i32 n, f32 const *rays, f32 const *pyramid, i32 exit_lanes, i32 mode,
+                                    f32 *out_t, i32 *out_tri, f32 *out_uv, u64 visits[2]) {
+  if (!d || n <= 0 || !rays || !out_t || !out_tri || !out_uv || !visits) return rt_fail("rt_test_trace_stream: bad arguments");
+  if (exit_lanes < 1 || exit_lanes > 64) return rt_fail("rt_test_trace_stream: exit_lanes %d outside [1, 64]", exit_lanes);
+  Device &D = *d->dev;
+  std::lock_guard<std::mutex> lock(D.mutex);
+  DeviceGuard guard(D);
+  if (ensure_device(D) != 0) return -1;
+  RT_KParams K;
+  scene_only_kparams(&K, d);
+  const int per_wave = (K.depth > 0 ? K.depth : 1) * 256 + 1536;
+  int room = (160 * 1024 - 16 * per_wave) / 208;
+  K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
+  if (!d->boxes_ordered || mode == 2) K.n_lds_nodes = 0;
+  K.pyr_nodes = K.n_lds_nodes;
+  // the short reciprocal is valid while |det| < 2^102: edges <= 2^38 (as for frames) and, here, ray directions <= 2^16
+  float dir_max = 0.0f;
+  for (i32 i = 0; i < n; i++)
+    for (int k = 3; k < 6; k++) {
+      float m = fabsf(rays[(size_t)i * 6 + k]);
+      if (!(m <= dir_max)) dir_max = m;
+    }
+  K.short_div = (mode != 1 && d->max_edge <= 0x1p38f && dir_max <= 0x1p16f) ? 1 : 0;
+  const int smem = K.n_lds_nodes * 208 + 16 * per_wave;
+  int n_blocks = (n + 16 * 64 * 4 - 1) / (16 * 64 * 4);                 // ~4 rays per lane
+  if (n_blocks > D.num_cus) n_blocks = D.num_cus;
+  if (n_blocks < 1) n_blocks = 1;
+  DevBuf br, bp, bt, btri, buv, bv;
+  HIP_TRY(br.alloc((size_t)n * 24));
+  HIP_TRY(bp.alloc(19 * 4));
+  HIP_TRY(bt.alloc((size_t)n * 4));
+  HIP_TRY(btri.alloc((size_t)n * 4));
+  HIP_TRY(buv.alloc((size_t)n * 8));
+  HIP_TRY(bv.alloc(16));
+  HIP_TRY(hipMemcpy(br.p, rays, (size_t)n * 24, hipMemcpyHostToDevice));
+  if (pyramid) HIP_TRY(hipMemcpy(bp.p, pyramid, 19 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(bv.p, 0, 16));
+  int rc = rt_launch_test_trace_stream(&K, n, br.as<float>(), pyramid ? bp.as<float>() : nullptr, exit_lanes, n_blocks, smem,
+                                       bt.as<float>(), btri.as<int>(), buv.as<float>(), bv.as<unsigned long long>(), nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(out_t, bt.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (rc == 0) rc = (int)hipMemcpy(out_tri, btri.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (rc == 0) rc = (int)hipMemcpy(out_uv, buv.p, (size_t)n * 8, hipMemcpyDeviceToHost);
+  if (rc == 0) rc = (int)hipMemcpy(visits, bv.p, 16, hipMemcpyDeviceToHost);
+  if (rc != 0) return rt_fail("rt_test_trace_stream failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
 extern "C" int rt_test_texture(RT_Device_Scene *d, i32 tex, i32 n, f32 const *uv, f32 *out_rgb) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (ensure_device() != 0) return -1;
   if (!d || n <= 0 || !uv || !out_rgb) return rt_fail("rt_test_texture: bad arguments");
+  Device &D = *d->dev;
+  std::lock_guard<std::mutex> lock(D.mutex);
+  DeviceGuard guard(D);
+  if (ensure_device(D) != 0) return -1;
   if (tex < 0) tex = d->bg_texture;
   if (tex >= d->n_textures) return rt_fail("rt_test_texture: texture %d of %d", tex, d->n_textures);
   RT_KParams K;

@@ -1001,6 +1001,160 @@ __device__ __forceinline__ RT_KArgs cold_args() {
   return p;
 }
 
+// ---- the traversal blocks of the path kernels -------------------------------------------------------------------------
+// ray_bvh_node_hit (raytracer.c:443-483) for the 64 rays of a wave, phase-scheduled: per round the wave runs ONE block --
+// LEAF (8-triangle test, raytracer.c:84-188) or NODE (8-box slab test + near-first order, raytracer.c:190-230, :459-468),
+// whichever more lanes wait for -- then every lane that finished a block pops its next child (raytracer.c:459-482) until
+// it knows its next block.  Returns when no lane traverses any more or when `exit_lanes` of the `n_trav0` lanes that
+// traversed at entry have finished (phase PH_HIT / PH_MISS).  This ONE function is the traversal of the tile-stream path
+// kernel (rt_kernels.hip), of the camera and trace kernels of the wavefront pipeline (rt_wavefront.hip) and of
+// rt_test_trace_stream_kernel (unit-level parity against oracle_trace_rays).
+//   PYRAMID: node blocks whose lanes are camera rays (`is_cam`) of the wave's tile about to enter ONE node test only the
+//            child boxes the tile's pyramid (LDS, pyr_off) can touch (pyramid_cull_mask, node_enter_few).
+struct TravState {
+  int      phase, level, node, child;
+  uint32_t cur, dirty, live;
+  HitRec   hit;
+};
+
+template <bool LDSN, bool SHORT_DIV, bool PYRAMID>
+__device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *smem, const float4 *lds_nodes, uint32_t *perm,
+                                                 const int lane, const int n_lds, const int pyr_nodes, const int pyr_off,
+                                                 const int leaf_level, const int exit_lanes, const int n_trav0, const Ray3 &ray,
+                                                 const bool is_cam, int &phase, int &level, int &node, int &child, uint32_t &cur,
+                                                 uint32_t &dirty, uint32_t &live, HitRec &hit, uint32_t &w_nodes, uint32_t &w_leaves) {
+  for (;;) {
+    const unsigned long long maskN = __ballot(phase == PH_NODE);
+    const int nN = (int)__popcll(maskN);
+    const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
+    if (nN + nL == 0 || n_trav0 - (nN + nL) >= exit_lanes) break;
+
+    if (nL >= nN) {
+      // ----- LEAF -----
+      w_leaves += (uint32_t)nL;
+#if RT_LEAF_PAIRS
+      {
+        const bool in_leaf = phase == PH_LEAF;
+        const int  g = child - P.last_row_offset;
+        if (leaf_test_pair<SHORT_DIV>(P, ray, g, in_leaf, hit)) dirty = 0xFFFFFFFFu;
+        if (in_leaf) phase = PH_POP;
+      }
+#else
+      if (phase == PH_LEAF) {
+        int  g = child - P.last_row_offset;
+        bool got = SHORT_DIV ? leaf_test_short_div(P, ray, g, hit) : leaf_test<false>(P, ray, g, hit);
+        if (got) dirty = 0xFFFFFFFFu;
+        phase = PH_POP;
+      }
+#endif
+    } else {
+      // ----- NODE -----
+      w_nodes += (uint32_t)nN;
+      const bool all_fast = (maskN & __ballot(!ray.fast)) == 0ull;
+      // camera rays of this tile about to enter the same node: test only the children their pyramid can touch.  When
+      // they are most of the block's lanes, the block runs for them alone; the others keep waiting for a node block.
+      uint32_t surv = 0xFFFFu;
+      bool in_blk = phase == PH_NODE;
+      if (PYRAMID) {
+        // (ballots of single comparisons combined with scalar ANDs: a ballot of a compound condition costs two more
+        // vector instructions)
+        const unsigned long long camN = maskN & __ballot(is_cam);
+        if (LDSN && all_fast && camN != 0ull) {
+          const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(camN));
+          const int nG = (int)__popcll(camN & __ballot(child == c0));
+          if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
+            // the mask depends on (tile, node) only and the tile's camera rays keep coming back to the same nodes
+            float *pyr = lds_at(smem, pyr_off);
+            uint32_t *slot = reinterpret_cast<uint32_t *>(pyr) + 32 + (c0 & 31);
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)*slot);
+            if ((ce >> 8) == (uint32_t)c0 + 1u) {
+              surv = 0xFFu & ~ce;
+            } else {
+              const uint32_t cull = pyramid_cull_mask(lds_nodes, pyr, c0);
+              if (lane_now() == 0) *slot = (((uint32_t)c0 + 1u) << 8) | cull;
+              surv = 0xFFu & ~cull;
+            }
+            if (__popc(surv) > 4) surv = 0xFFFFu;
+            else { in_blk = phase == PH_NODE && is_cam && child == c0; w_nodes -= (uint32_t)(nN - nG); }
+          }
+        }
+      }
+      if (in_blk) {
+        if (level >= 0) {
+          perm[level * 64 + lane] = cur;
+          live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
+        }
+        node = child;
+        level += 1;
+        if (PYRAMID && surv <= 0xFFu) {
+          cur = surv ? node_enter_few(ray, lds_nodes, node, surv, hit.t) : 0u;
+        } else if (all_fast) {
+          if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
+          else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+        } else {
+          cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+        }
+        dirty &= ~(1u << level);
+        if (cur >> 24) {
+          child = 8 * node + 1 + (int)(cur & 7u);
+          cur = ((cur >> 3) & 0x1FFFFFu) | (((cur >> 24) - 1u) << 24);
+          phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
+        } else {
+          phase = PH_POP;
+        }
+      }
+    }
+
+    // ----- pops: every lane that just finished a block takes its next child / goes up -----
+    while (__any(phase == PH_POP)) {
+      if (phase == PH_POP) {
+        uint32_t cnt = cur >> 24;
+        if (cnt == 0 || level < 0) {
+          // go up to the nearest level that still has children to visit -- in one step: the k-th ancestor of node n in the
+          // implicit 8-ary tree is (n - (8^k - 1)/7) >> 3k, and (8^k - 1)/7 is k ones 3 bits apart
+          uint32_t above = (level > 0) ? (live & ((1u << level) - 1u)) : 0u;
+          if (above == 0u) {
+            level = -1;
+            phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
+          } else {
+            int target = 31 - __clz((int)above);
+            int k3 = 3 * (level - target);
+            node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
+            level = target;
+            cur = perm[level * 64 + lane];
+            cnt = cur >> 24;
+          }
+        }
+        if (phase == PH_POP) {
+          int j = (int)(cur & 7u);
+          cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
+          bool go = true;
+          if ((dirty >> level) & 1u) {
+            float dj;
+            if (LDSN && node < n_lds) {
+              // entry distance from the three NEAR planes, picked by address (see NODE_LDS_ORDERED); the rays that are
+              // not NaN-free -- a lane in a blue moon -- redo it through the min / max form
+              const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
+              const float sx = (*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)) - ray.o.x) * ray.inv_x;
+              const float sy = (*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)) - ray.o.y) * ray.inv_y;
+              const float sz = (*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)) - ray.o.z) * ray.inv_z;
+              dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+              if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
+            } else {
+              dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
+            }
+            if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
+          }
+          if (go) {
+            child = 8 * node + 1 + j;
+            phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
+          }
+        }
+      }
+    }
+  }
+}
+
 struct ShadeParams {            // what shade_hit / background_lookup read (same field names as RT_KParams)
   const float *tris, *mats;
   const RT_DTexture *textures;

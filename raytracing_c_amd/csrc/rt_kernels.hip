@@ -470,153 +470,12 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       }
 
       // ================= traversal: NODE / LEAF blocks until `thresh` lanes wait for S =================
-      for (;;) {
-        const unsigned long long maskN = __ballot(phase == PH_NODE);
-        const int nN = (int)__popcll(maskN);
-        const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
-        // while the tile still hands out paths, wait until `thresh` lanes want the S block (dense shading); once it is
-        // exhausted nothing refills the lanes, and what matters is the latency of the remaining paths' bounce chains:
-        // shade as soon as `drain_thresh` lanes wait
-        if (nN + nL == 0 || n_trav0 - (nN + nL) >= (tile_open ? thresh : drain_thresh)) break;
-
-        if (nL >= nN) {
-          // ----- LEAF -----
-          w_leaves += (uint32_t)nL;
-#if RT_LEAF_PAIRS
-          {
-            const bool in_leaf = phase == PH_LEAF;
-            const int  g = child - P.last_row_offset;
-            if (leaf_test_pair<SHORT_DIV>(P, ray, g, in_leaf, hit)) dirty = 0xFFFFFFFFu;
-            if (in_leaf) phase = PH_POP;
-          }
-#else
-          if (phase == PH_LEAF) {
-            int  g = child - P.last_row_offset;
-            bool got = SHORT_DIV ? leaf_test_short_div(P, ray, g, hit) : leaf_test<false>(P, ray, g, hit);
-            if (got) dirty = 0xFFFFFFFFu;
-            phase = PH_POP;
-          }
-#endif
-        } else {
-          // ----- NODE -----
-          w_nodes += (uint32_t)nN;
-          const bool all_fast = (maskN & __ballot(!ray.fast)) == 0ull;
-#ifdef RT_EXP_NODESTATS
-          {
-            unsigned long long act = __ballot(phase == PH_NODE), cam = __ballot(phase == PH_NODE && bounce == 0);
-            xs[0] += 1; xs[1] += (uint32_t)nN; xs[2] += (uint32_t)__popcll(cam);
-            if (cam) {
-              int first = (int)__builtin_ctzll(cam);
-              int c0 = __builtin_amdgcn_readlane(child, first), p0 = __builtin_amdgcn_readlane(pix >> 1, first);
-              unsigned long long grp = __ballot(phase == PH_NODE && bounce == 0 && child == c0 && (pix >> 1) == p0);
-              unsigned long long grt = __ballot(phase == PH_NODE && bounce == 0 && child == c0);
-              xs[3] += (uint32_t)__popcll(grp); if (grp == act) xs[4] += 1;
-              if (2 * (int)__popcll(grp) >= nN) xs[5] += 1;
-              xs[7] += (uint32_t)__popcll(grt); if (grt == act) xs[8] += 1;
-            } else xs[6] += 1;
-          }
-#endif
-          // camera rays of this tile about to enter the same node: test only the children their pyramid can touch.  When
-          // they are most of the block's lanes, the block runs for them alone; the others keep waiting for a node block.
-          uint32_t surv = 0xFFFFu;
-          bool in_blk = phase == PH_NODE;
-          // (ballots of single comparisons combined with scalar ANDs: a ballot of a compound condition costs two more
-          // vector instructions)
-          const unsigned long long camN = maskN & __ballot(bounce == 0);
-          if (LDSN && all_fast && camN != 0ull) {
-            const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(camN));
-            const int nG = (int)__popcll(camN & __ballot(child == c0));
-            if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
-              // the mask depends on (tile, node) only and the tile's camera rays keep coming back to the same nodes
-              float *pyr = lds_at(smem, pyr_off);
-              uint32_t *slot = reinterpret_cast<uint32_t *>(pyr) + 32 + (c0 & 31);
-              const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)*slot);
-              if ((ce >> 8) == (uint32_t)c0 + 1u) {
-                surv = 0xFFu & ~ce;
-              } else {
-                const uint32_t cull = pyramid_cull_mask(lds_nodes, pyr, c0);
-                if (lane_now() == 0) *slot = (((uint32_t)c0 + 1u) << 8) | cull;
-                surv = 0xFFu & ~cull;
-              }
-              if (__popc(surv) > 4) surv = 0xFFFFu;
-              else { in_blk = phase == PH_NODE && bounce == 0 && child == c0; w_nodes -= (uint32_t)(nN - nG); }
-#ifdef RT_EXP_NODESTATS
-              xs[9 + (surv == 0xFFFFu ? 5 : (int)__popc(surv))] += 1;
-#endif
-            }
-          }
-          if (in_blk) {
-            if (level >= 0) {
-              perm[level * 64 + lane] = cur;
-              live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
-            }
-            node = child;
-            level += 1;
-            if (surv <= 0xFFu) {
-              cur = surv ? node_enter_few(ray, lds_nodes, node, surv, hit.t) : 0u;
-            } else if (all_fast) {
-              if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
-              else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
-            } else {
-              cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
-            }
-            dirty &= ~(1u << level);
-            if (cur >> 24) {
-              child = 8 * node + 1 + (int)(cur & 7u);
-              cur = ((cur >> 3) & 0x1FFFFFu) | (((cur >> 24) - 1u) << 24);
-              phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
-            } else {
-              phase = PH_POP;
-            }
-          }
-        }
-
-        // ----- pops: every lane that just finished a block takes its next child / goes up -----
-        while (__any(phase == PH_POP)) {
-          if (phase == PH_POP) {
-            uint32_t cnt = cur >> 24;
-            if (cnt == 0 || level < 0) {
-              uint32_t above = (level > 0) ? (live & ((1u << level) - 1u)) : 0u;
-              if (above == 0u) {
-                level = -1;
-                phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
-              } else {
-                int target = 31 - __clz((int)above);
-                int k3 = 3 * (level - target);
-                node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
-                level = target;
-                cur = perm[level * 64 + lane];
-                cnt = cur >> 24;
-              }
-            }
-            if (phase == PH_POP) {
-              int j = (int)(cur & 7u);
-              cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
-              bool go = true;
-              if ((dirty >> level) & 1u) {
-                float dj;
-                if (LDSN && node < n_lds) {
-                  // entry distance from the three NEAR planes, picked by address (see NODE_LDS_ORDERED); the rays that are
-                  // not NaN-free -- a lane in a blue moon -- redo it through the min / max form
-                  const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
-                  const float sx = (*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)) - ray.o.x) * ray.inv_x;
-                  const float sy = (*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)) - ray.o.y) * ray.inv_y;
-                  const float sz = (*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)) - ray.o.z) * ray.inv_z;
-                  dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
-                  if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
-                } else {
-                  dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
-                }
-                if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
-              }
-              if (go) {
-                child = 8 * node + 1 + j;
-                phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
-              }
-            }
-          }
-        }
-      }
+      // while the tile still hands out paths, wait until `thresh` lanes want the S block (dense shading); once it is
+      // exhausted nothing refills the lanes, and what matters is the latency of the remaining paths' bounce chains:
+      // shade as soon as `drain_thresh` lanes wait
+      traversal_blocks<LDSN, SHORT_DIV, true>(P, smem, lds_nodes, perm, lane, n_lds, pyr_nodes, pyr_off, leaf_level,
+                                              tile_open ? thresh : drain_thresh, n_trav0, ray, bounce == 0, phase, level, node,
+                                              child, cur, dirty, live, hit, w_nodes, w_leaves);
     }
 
     // ---------------- flush the wave's share of the tile: lane p owns pixel p ----------------
@@ -840,9 +699,12 @@ extern "C" int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n
 }
 
 // ---------------------------------------------------------------------------------
-// Tile order for the next launch: counting sort of the tiles by descending cost bucket (4 buckets per
-// power of two of last launch's ray count).  Order inside a bucket is whatever the atomics give: only the
-// schedule depends on it, never a pixel (order-free accumulation).
+// Per-launch preparation in ONE launch of one workgroup: zero the ray counters and the work head, reset every tile's unit
+// counter and the open-tile count of every group of 64 tiles, zero the cost buffer this launch will fill, and -- when the
+// previous launch of the same view left its costs -- the tile order of this one: counting sort of the tiles by descending
+// cost bucket (4 buckets per power of two of that launch's ray count; order inside a bucket is whatever the LDS atomics give:
+// only the schedule depends on it, never a pixel).  Round 2 spent three memsets and five small kernels on this, ~25 us
+// of launch gaps per frame -- a fifth of a frame at the reference's default size (1024 x 1024, 16 spp).
 #define RT_ORDER_BUCKETS 132
 __device__ __forceinline__ int cost_bucket(uint32_t c) {
   if (c < 4u) return (int)c;                               // 0..3
@@ -850,53 +712,46 @@ __device__ __forceinline__ int cost_bucket(uint32_t c) {
   return 4 * (e - 1) + (int)((c >> (e - 2)) & 3u);         // 4..131, monotonic in c
 }
 
-// (most tiles of a frame fall into a handful of buckets: the counters are combined per workgroup in LDS first,
-//  one global atomic per bucket and workgroup -- a global atomic per tile serialises on those few addresses)
-__global__ void rt_order_hist_kernel(int n, const uint32_t *cost, uint32_t *hist) {
-  __shared__ uint32_t local[RT_ORDER_BUCKETS];
-  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x) local[b] = 0;
-  __syncthreads();
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&local[cost_bucket(cost[i])], 1u);
-  __syncthreads();
-  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x)
-    if (local[b]) atomicAdd(&hist[b], local[b]);
-}
-
-__global__ void rt_order_scan_kernel(uint32_t *hist) {      // one thread: start offset of every bucket, expensive first
-  uint32_t run = 0;
-  for (int b = RT_ORDER_BUCKETS - 1; b >= 0; b--) {
-    uint32_t c = hist[b];
-    hist[b] = run;
-    run += c;
+__global__ __launch_bounds__(1024) void rt_prepare_kernel(int n_tiles, uint32_t *tile_next, uint32_t *open_groups,
+                                                          unsigned long long *counters, uint32_t *work_head, uint32_t *cost_cur,
+                                                          const uint32_t *cost_prev, uint32_t *order) {
+  __shared__ uint32_t hist[RT_ORDER_BUCKETS];
+  const int tid = threadIdx.x;
+  if (tid < RT_N_COUNTERS) counters[tid] = 0ull;
+  if (tid < 16) work_head[tid] = 0u;
+  for (int i = tid; i < n_tiles; i += 1024) {
+    if (tile_next) tile_next[i] = 0u;
+    if (cost_cur) cost_cur[i] = 0u;
   }
-}
-
-__global__ void rt_order_scatter_kernel(int n, const uint32_t *cost, uint32_t *cursor, uint32_t *order) {
-  __shared__ uint32_t local[RT_ORDER_BUCKETS], base[RT_ORDER_BUCKETS];
-  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x) local[b] = 0;
+  if (open_groups) {
+    const int n_groups = (n_tiles + 63) >> 6;
+    for (int g = tid; g < n_groups; g += 1024) {
+      int left = n_tiles - g * 64;
+      open_groups[g] = (uint32_t)(left < 64 ? left : 64);
+    }
+  }
+  if (!cost_prev || !order) return;
+  for (int b = tid; b < RT_ORDER_BUCKETS; b += 1024) hist[b] = 0u;
   __syncthreads();
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int bucket = 0;
-  uint32_t pos = 0;
-  if (i < n) {
-    bucket = cost_bucket(cost[i]);
-    pos = atomicAdd(&local[bucket], 1u);                   // rank inside this workgroup's share of the bucket
+  for (int i = tid; i < n_tiles; i += 1024) atomicAdd(&hist[cost_bucket(cost_prev[i])], 1u);
+  __syncthreads();
+  if (tid == 0) {                                          // start offset of every bucket, expensive first
+    uint32_t run = 0;
+    for (int b = RT_ORDER_BUCKETS - 1; b >= 0; b--) {
+      uint32_t c = hist[b];
+      hist[b] = run;
+      run += c;
+    }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < RT_ORDER_BUCKETS; b += blockDim.x)
-    base[b] = local[b] ? atomicAdd(&cursor[b], local[b]) : 0u;   // reserve the workgroup's range once per bucket
-  __syncthreads();
-  if (i < n) order[base[bucket] + pos] = (uint32_t)i;
+  for (int i = tid; i < n_tiles; i += 1024) order[atomicAdd(&hist[cost_bucket(cost_prev[i])], 1u)] = (uint32_t)i;
 }
 
-extern "C" int rt_launch_tile_order(int n_tiles, const uint32_t *cost, uint32_t *hist, uint32_t *order, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(hist, 0, RT_ORDER_BUCKETS * sizeof(uint32_t), stream);
-  if (e != hipSuccess) return (int)e;
-  int blocks = (n_tiles + 255) / 256;
-  hipLaunchKernelGGL(rt_order_hist_kernel, dim3(blocks), dim3(256), 0, stream, n_tiles, cost, hist);
-  hipLaunchKernelGGL(rt_order_scan_kernel, dim3(1), dim3(1), 0, stream, hist);
-  hipLaunchKernelGGL(rt_order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, n_tiles, cost, hist, order);
+extern "C" int rt_launch_prepare(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, unsigned long long *counters,
+                                 uint32_t *work_head, uint32_t *cost_cur, const uint32_t *cost_prev, uint32_t *order,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL(rt_prepare_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, tile_next, open_groups, counters, work_head, cost_cur,
+                     cost_prev, order);
   return (int)hipGetLastError();
 }
 
@@ -1010,24 +865,106 @@ __global__ void rt_test_texture_kernel(RT_KParams P, int tex, int n, const float
   out[i * 3 + 2] = c.z;
 }
 
-// ---------------------------------------------------------------------------------
-// launchers (called from rt_api.cpp)
+// Arbitrary rays through the PRODUCTION traversal: traversal_blocks() -- the NODE / LEAF / pop code of the path kernels --
+// in the path kernel's workgroup geometry (16 waves, tree in LDS, per-wave perm stacks), lanes refilled from the ray list
+// as they finish, blocks mixed exactly as a frame mixes them.  With a pyramid (`pyr`: 4 outward plane normals at
+// [4 q .. 4 q + 2], the common ray origin at [16 .. 18]) every ray counts as a camera ray of one tile: node blocks take
+// the culled form (pyramid_cull_mask, node_enter_few) whenever the path kernel would.  visits[0 / 1] += node / leaf
+// visits (raytracer.c:452 / :476 calls).  Compared with oracle_trace_rays_counted() by tests/test_gpu_trace_stream.py.
+template <bool SHORT_DIV, bool PYRAMID>
+__global__ __launch_bounds__(16 * 64, 1) void rt_test_trace_stream_kernel(RT_KParams P, int n, const float *rays, const float *pyr_in,
+                                                                         int exit_lanes, float *out_t, int *out_tri, float *out_uv,
+                                                                         unsigned long long *visits) {
+  extern __shared__ float4 smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n_lds = P.n_lds_nodes;
+  const float4 *lds_nodes = smem;
+  const int perm_f4 = (P.depth > 0 ? P.depth : 1) * 16;
+  uint32_t *perm = reinterpret_cast<uint32_t *>(smem + n_lds * RT_LDS_NODE_F4 + wave * (perm_f4 + 96));
+  const int pyr_off = (n_lds * RT_LDS_NODE_F4 + __builtin_amdgcn_readfirstlane(wave) * (perm_f4 + 96) + perm_f4 - 16) * 16;
+  {
+    const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
+    for (int i = threadIdx.x; i < n_lds * 12; i += 16 * 64) {
+      int nd = i / 12, q = i - nd * 12;
+      smem[nd * RT_LDS_NODE_F4 + q] = g[i];
+    }
+    __syncthreads();
+  }
+  if (PYRAMID) {
+    float *pyr = lds_at(smem, pyr_off);
+    if (lane < 19) pyr[lane] = pyr_in[lane];
+    if (lane < 32) reinterpret_cast<uint32_t *>(pyr)[32 + lane] = 0u;
+  }
+  const int leaf_level = P.depth - 1;
+  const int n_waves = (int)gridDim.x * 16, wave_id = (int)blockIdx.x * 16 + wave;
+  const int per_wave = (n + n_waves - 1) / n_waves;
+  int next = wave_id * per_wave;                                   // this wave's slice of the ray list
+  const int end = next + per_wave < n ? next + per_wave : n;
 
-// per launch: no chunk handed out yet; every group of 64 tiles is open
-__global__ void rt_stream_init_kernel(int n_tiles, uint32_t *tile_next, uint32_t *open_groups) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_tiles) tile_next[i] = 0u;
-  int n_groups = (n_tiles + 63) >> 6;
-  if (i < n_groups) {
-    int left = n_tiles - i * 64;
-    open_groups[i] = (uint32_t)(left < 64 ? left : 64);
+  int   phase = PH_NEED, idx = 0;
+  Ray3  ray;
+  ray_setup(ray, rt_v3_make(0, 0, 0), rt_v3_make(0, 0, 1));
+  int   level = -1, node = 0, child = 0;
+  uint32_t cur = 0, dirty = 0, live = 0, w_nodes = 0, w_leaves = 0;
+  HitRec hit;
+  hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+  for (;;) {
+    if (phase == PH_HIT || phase == PH_MISS) {
+      out_t[idx] = hit.t;
+      out_tri[idx] = hit.tri;
+      out_uv[idx * 2 + 0] = hit.u;
+      out_uv[idx * 2 + 1] = hit.v;
+      phase = PH_NEED;
+    }
+    if (next < end) {
+      const unsigned long long need = __ballot(phase == PH_NEED);
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      if (phase == PH_NEED && next + rank < end) {
+        idx = next + rank;
+        const float *r = rays + (size_t)idx * 6;
+        ray_setup<SHORT_DIV>(ray, rt_v3_make(r[0], r[1], r[2]), rt_v3_make(r[3], r[4], r[5]));
+        hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
+        dirty = 0; live = 0; cur = 0; level = -1; node = 0;
+        child = (leaf_level >= 0) ? 0 : P.last_row_offset;
+        phase = (leaf_level >= 0) ? PH_NODE : PH_LEAF;
+      }
+      next += (int)__popcll(need);
+    }
+    const int n_trav0 = (int)__popcll(__ballot(phase == PH_NODE || phase == PH_LEAF));
+    if (n_trav0 == 0) {
+      if (next >= end) break;
+      continue;
+    }
+    traversal_blocks<true, SHORT_DIV, PYRAMID>(P, smem, lds_nodes, perm, lane, n_lds, PYRAMID ? P.pyr_nodes : 0, pyr_off, leaf_level,
+                                               next < end ? exit_lanes : 1, n_trav0, ray, true, phase, level, node, child, cur, dirty,
+                                               live, hit, w_nodes, w_leaves);
+  }
+  if (lane == 0) {
+    atomicAdd(visits + 0, (unsigned long long)w_nodes);
+    atomicAdd(visits + 1, (unsigned long long)w_leaves);
   }
 }
 
-extern "C" int rt_launch_stream_init(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, hipStream_t stream) {
-  hipLaunchKernelGGL(rt_stream_init_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, n_tiles, tile_next, open_groups);
+extern "C" int rt_launch_test_trace_stream(const RT_KParams *P, int n, const float *rays, const float *pyr, int exit_lanes, int n_blocks,
+                                           int smem_bytes, float *out_t, int *out_tri, float *out_uv, unsigned long long *visits,
+                                           hipStream_t stream) {
+#define RT_TTS(SD, PY)                                                                                                          \
+  do {                                                                                                                          \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_test_trace_stream_kernel<SD, PY>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                 \
+    if (e != hipSuccess) return (int)e;                                                                                         \
+    hipLaunchKernelGGL((rt_test_trace_stream_kernel<SD, PY>), dim3(n_blocks), dim3(16 * 64), smem_bytes, stream, *P, n, rays,  \
+                       pyr, exit_lanes, out_t, out_tri, out_uv, visits);                                                        \
+  } while (0)
+  if (P->short_div) { if (pyr) RT_TTS(true, true); else RT_TTS(true, false); }
+  else { if (pyr) RT_TTS(false, true); else RT_TTS(false, false); }
+#undef RT_TTS
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------
+// launchers (called from rt_api.cpp)
 
 template <int WAVES, bool LDSN, int MINW, bool SHORT_DIV>
 static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipStream_t stream) {

@@ -412,121 +412,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_wf_camera_k
       }
 
       // ================= traversal: NODE / LEAF blocks until `thresh` lanes wait for S =================
-      for (;;) {
-        const unsigned long long maskN = __ballot(phase == PH_NODE);
-        const int nN = (int)__popcll(maskN);
-        const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
-        if (nN + nL == 0 || n_trav0 - (nN + nL) >= thresh) break;
-
-        if (nL >= nN) {
-          w_leaves += (uint32_t)nL;
-#if RT_LEAF_PAIRS
-          {
-            const bool in_leaf = phase == PH_LEAF;
-            const int  g = child - P.last_row_offset;
-            if (leaf_test_pair<SHORT_DIV>(P, ray, g, in_leaf, hit)) dirty = 0xFFFFFFFFu;
-            if (in_leaf) phase = PH_POP;
-          }
-#else
-          if (phase == PH_LEAF) {
-            int  g = child - P.last_row_offset;
-            bool got = SHORT_DIV ? leaf_test_short_div(P, ray, g, hit) : leaf_test<false>(P, ray, g, hit);
-            if (got) dirty = 0xFFFFFFFFu;
-            phase = PH_POP;
-          }
-#endif
-        } else {
-          w_nodes += (uint32_t)nN;
-          const bool all_fast = (maskN & __ballot(!ray.fast)) == 0ull;
-          uint32_t surv = 0xFFFFu;
-          bool in_blk = phase == PH_NODE;
-          if (LDSN && all_fast) {
-            const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(maskN));
-            const int nG = (int)__popcll(maskN & __ballot(child == c0));
-            if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
-              float *pyr = lds_at(smem, pyr_off);
-              uint32_t *slot = reinterpret_cast<uint32_t *>(pyr) + 32 + (c0 & 31);
-              const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)*slot);
-              if ((ce >> 8) == (uint32_t)c0 + 1u) {
-                surv = 0xFFu & ~ce;
-              } else {
-                const uint32_t cull = pyramid_cull_mask(lds_nodes, pyr, c0);
-                if (lane_now() == 0) *slot = (((uint32_t)c0 + 1u) << 8) | cull;
-                surv = 0xFFu & ~cull;
-              }
-              if (__popc(surv) > 4) surv = 0xFFFFu;
-              else { in_blk = phase == PH_NODE && child == c0; w_nodes -= (uint32_t)(nN - nG); }
-            }
-          }
-          if (in_blk) {
-            if (level >= 0) {
-              perm[level * 64 + lane] = cur;
-              live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
-            }
-            node = child;
-            level += 1;
-            if (surv <= 0xFFu) {
-              cur = surv ? node_enter_few(ray, lds_nodes, node, surv, hit.t) : 0u;
-            } else if (all_fast) {
-              if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
-              else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
-            } else {
-              cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
-            }
-            dirty &= ~(1u << level);
-            if (cur >> 24) {
-              child = 8 * node + 1 + (int)(cur & 7u);
-              cur = ((cur >> 3) & 0x1FFFFFu) | (((cur >> 24) - 1u) << 24);
-              phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
-            } else {
-              phase = PH_POP;
-            }
-          }
-        }
-
-        while (__any(phase == PH_POP)) {
-          if (phase == PH_POP) {
-            uint32_t cnt = cur >> 24;
-            if (cnt == 0 || level < 0) {
-              uint32_t above = (level > 0) ? (live & ((1u << level) - 1u)) : 0u;
-              if (above == 0u) {
-                level = -1;
-                phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
-              } else {
-                int target = 31 - __clz((int)above);
-                int k3 = 3 * (level - target);
-                node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
-                level = target;
-                cur = perm[level * 64 + lane];
-                cnt = cur >> 24;
-              }
-            }
-            if (phase == PH_POP) {
-              int j = (int)(cur & 7u);
-              cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
-              bool go = true;
-              if ((dirty >> level) & 1u) {
-                float dj;
-                if (LDSN && node < n_lds) {
-                  const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
-                  const float sx = (*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)) - ray.o.x) * ray.inv_x;
-                  const float sy = (*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)) - ray.o.y) * ray.inv_y;
-                  const float sz = (*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)) - ray.o.z) * ray.inv_z;
-                  dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
-                  if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
-                } else {
-                  dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
-                }
-                if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
-              }
-              if (go) {
-                child = 8 * node + 1 + j;
-                phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
-              }
-            }
-          }
-        }
-      }
+      traversal_blocks<LDSN, SHORT_DIV, true>(P, smem, lds_nodes, perm, lane, n_lds, pyr_nodes, pyr_off, leaf_level, thresh,
+                                              n_trav0, ray, true, phase, level, node, child, cur, dirty, live, hit, w_nodes, w_leaves);
     }
 
     // ---------------- flush the wave's share of the tile: lane p owns pixel p ----------------
@@ -736,99 +623,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_wf_trace_ke
       continue;
     }
 
-    for (;;) {
-      const unsigned long long maskN = __ballot(phase == PH_NODE);
-      const int nN = (int)__popcll(maskN);
-      const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
-      if (nN + nL == 0 || n_trav0 - (nN + nL) >= thresh) break;
-
-      if (nL >= nN) {
-        w_leaves += (uint32_t)nL;
-#if RT_LEAF_PAIRS
-        {
-          const bool in_leaf = phase == PH_LEAF;
-          const int  g = child - P.last_row_offset;
-          if (leaf_test_pair<SHORT_DIV>(P, ray, g, in_leaf, hit)) dirty = 0xFFFFFFFFu;
-          if (in_leaf) phase = PH_POP;
-        }
-#else
-        if (phase == PH_LEAF) {
-          int  g = child - P.last_row_offset;
-          bool got = SHORT_DIV ? leaf_test_short_div(P, ray, g, hit) : leaf_test<false>(P, ray, g, hit);
-          if (got) dirty = 0xFFFFFFFFu;
-          phase = PH_POP;
-        }
-#endif
-      } else {
-        w_nodes += (uint32_t)nN;
-        const bool all_fast = (maskN & __ballot(!ray.fast)) == 0ull;
-        if (phase == PH_NODE) {
-          if (level >= 0) {
-            perm[level * 64 + lane] = cur;
-            live = (cur >> 24) ? (live | (1u << level)) : (live & ~(1u << level));
-          }
-          node = child;
-          level += 1;
-          if (all_fast) {
-            if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
-            else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
-          } else {
-            cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
-          }
-          dirty &= ~(1u << level);
-          if (cur >> 24) {
-            child = 8 * node + 1 + (int)(cur & 7u);
-            cur = ((cur >> 3) & 0x1FFFFFu) | (((cur >> 24) - 1u) << 24);
-            phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
-          } else {
-            phase = PH_POP;
-          }
-        }
-      }
-
-      while (__any(phase == PH_POP)) {
-        if (phase == PH_POP) {
-          uint32_t cnt = cur >> 24;
-          if (cnt == 0 || level < 0) {
-            uint32_t above = (level > 0) ? (live & ((1u << level) - 1u)) : 0u;
-            if (above == 0u) {
-              level = -1;
-              phase = (hit.tri >= 0) ? PH_HIT : PH_MISS;
-            } else {
-              int target = 31 - __clz((int)above);
-              int k3 = 3 * (level - target);
-              node = (int)(((uint32_t)node - (0x09249249u & ((1u << k3) - 1u))) >> k3);
-              level = target;
-              cur = perm[level * 64 + lane];
-              cnt = cur >> 24;
-            }
-          }
-          if (phase == PH_POP) {
-            int j = (int)(cur & 7u);
-            cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
-            bool go = true;
-            if ((dirty >> level) & 1u) {
-              float dj;
-              if (LDSN && node < n_lds) {
-                const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
-                const float sx = (*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)) - ray.o.x) * ray.inv_x;
-                const float sy = (*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)) - ray.o.y) * ray.inv_y;
-                const float sz = (*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)) - ray.o.z) * ray.inv_z;
-                dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
-                if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
-              } else {
-                dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
-              }
-              if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
-            }
-            if (go) {
-              child = 8 * node + 1 + j;
-              phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
-            }
-          }
-        }
-      }
-    }
+    traversal_blocks<LDSN, SHORT_DIV, false>(P, smem, lds_nodes, perm, lane, n_lds, 0, 0, leaf_level, thresh, n_trav0, ray, false,
+                                             phase, level, node, child, cur, dirty, live, hit, w_nodes, w_leaves);
   }
 
   RT_KArgs A = cold_args();

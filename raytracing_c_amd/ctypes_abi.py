@@ -120,6 +120,11 @@ class RT_Counters(C.Structure):  # rt_hip.h
                 ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured")]
 
 
+class RT_Frame_Timing(C.Structure):  # rt_hip.h
+    _fields_ = [(n, C.c_float) for n in
+                ("stamp_ms", "upload_ms", "enqueue_ms", "gpu_prep_ms", "gpu_path_ms", "gpu_resolve_ms", "gpu_copy_ms", "total_ms")]
+
+
 class RT_Render_Params(C.Structure):  # rt_hip.h
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("max_bounces", C.c_int32),
                 ("seed", C.c_uint32), ("rank", C.c_int32), ("world", C.c_int32), ("slab", C.c_int32),
@@ -148,6 +153,8 @@ EXPORTED_SYMBOLS = [
     "disney_shader_proc", "debug_shader_proc", "sample_background",
     # rt_hip.h
     "rt_last_error", "rt_clear_error", "rt_init", "rt_set_seed", "rt_get_seed",
+    "rt_set_devices", "rt_device_count", "rt_set_pipeline", "rt_get_pipeline", "rt_set_wavefront_capacity",
+    "rt_scene_verify", "rt_get_frame_timing", "rt_test_trace_stream",
     "rt_scene_upload", "rt_scene_release", "rt_scene_invalidate", "rt_scene_device_bytes", "rt_set_camera",
     "rt_chunk_count", "rt_chunk_owner", "rt_local_chunk_count", "rt_max_local_chunk_count", "rt_local_chunk_list", "rt_render_accumulate", "rt_resolve", "rt_untile",
     "rt_denoise", "rt_render_frame", "rt_get_counters", "rt_get_sched_stats", "rt_get_wave_times", "rt_last_kernel_ms", "rt_kernel_timing_reset", "rt_kernel_timing_mean_ms",

@@ -125,6 +125,15 @@ def _declare(d):
     d.rt_test_quantize_sweep.argtypes = [vp]
     d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    d.rt_test_trace_stream.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    d.rt_set_devices.argtypes = [C.c_int32, C.c_int32]
+    d.rt_device_count.restype = C.c_int32
+    d.rt_set_pipeline.argtypes = [C.c_int32]
+    d.rt_get_pipeline.restype = C.c_int32
+    d.rt_set_wavefront_capacity.argtypes = [C.c_int64]
+    d.rt_set_wavefront_capacity.restype = None
+    d.rt_scene_verify.argtypes = [P(abi.Scene)]
+    d.rt_get_frame_timing.argtypes = [P(abi.RT_Frame_Timing)]
     d.render_thread_proc.argtypes = [P(abi.Rendering_Context)]
     d.render_thread_proc.restype = None
     d.rendering_context_is_finished.argtypes = [P(abi.Rendering_Context)]

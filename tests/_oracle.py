@@ -58,6 +58,8 @@ def load(path=None):
     d.oracle_ray_scene_hit.restype = None
     d.oracle_trace_rays.argtypes = [P(abi.Scene), C.c_int32, vp, vp, vp, vp]
     d.oracle_trace_rays.restype = None
+    d.oracle_trace_rays_counted.argtypes = [P(abi.Scene), C.c_int32, vp, vp, vp, vp, vp]
+    d.oracle_trace_rays_counted.restype = None
     d.oracle_sample_texture_bilinear.argtypes = [P(abi.Image), C.c_float, C.c_float, vp]
     d.oracle_sample_texture_bilinear.restype = None
     d.oracle_sample_background.argtypes = [P(abi.Image), vp, vp]

@@ -255,49 +255,6 @@ def test_frame_bit_exact(rt, oracle, name, w, h, s, b, shader):
     assert want["image"].std() > 1.0, "frame must not be blank"
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5])
-def test_every_kernel_variant_is_bit_exact(rt, oracle, variant, monkeypatch):
-    """RT_KERNEL=1 plain while-while kernel, 2 phase-scheduled, 3 phase-scheduled + BVH top in LDS, 5 tile streams (default)."""
-    from raytracing_c_amd.configs import load_config
-    from tests import _oracle
-    monkeypatch.setenv("RT_KERNEL", str(variant))
-    for name, w, h, s, b in (("helmet", 96, 54, 6, 8), ("quad", 40, 40, 4, 3)):
-        hs, _ = load_config(name)
-        want = _oracle.render(hs, w, h, s, b)
-        got = rt.render_frame(hs, w, h, s, b, want_accum=True)
-        assert np.array_equal(want["accum"], got["accum"])
-        c = got["counters"]
-        assert (c.rays, c.node_visits, c.leaf_visits, c.shades) == tuple(
-            want["counters"][k] for k in ("rays", "node_visits", "leaf_visits", "shades"))
-
-
-@pytest.mark.parametrize("knobs", [{"RT_SCHED_THRESH": "1"}, {"RT_SCHED_THRESH": "64"}, {"RT_LDS_NODES": "9"},
-                                   {"RT_LDS_NODES": "0"}, {"RT_WAVES_PER_CU": "1"}, {"RT_ORDER": "identity"},
-                                   {"RT_GRAB": "1"}, {"RT_GRAB": "4"}, {"RT_DRAIN_THRESH": "1"}, {"RT_PYRAMID": "0"}, {"RT_SHORT_DIV": "0"}, {"RT_PARK": "0"},
-                                   {"RT_KERNEL": "3", "RT_SCHED_THRESH": "16"}])
-def test_scheduling_knobs_do_not_change_the_image(rt, oracle, knobs, monkeypatch):
-    """Scheduling is free to change; results are not (order-free fixed-point accumulation)."""
-    from raytracing_c_amd.configs import load_config
-    from tests import _oracle
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
-    hs, _ = load_config("helmet")
-    want = _oracle.render(hs, 80, 45, 5, 8)
-    for slab in (0, 1, 4, 64):
-        lib_p = dict(width=80, height=45)
-        from raytracing_c_amd import ctypes_abi as abi
-        import torch
-        d = rt.lib.rt_scene_upload(C.byref(hs.scene))
-        try:
-            accum = torch.zeros((45, 80, 3), dtype=torch.int64, device="cuda")
-            p = abi.RT_Render_Params(80, 45, 5, 8, 0x1234ABCD, 0, 1, slab, 0)
-            assert rt.lib.rt_render_accumulate(d, C.byref(p), accum.data_ptr(), None) == 0, rt.last_error()
-            torch.cuda.synchronize()
-            assert np.array_equal(accum.cpu().numpy().view(np.uint64), want["accum"]), (knobs, slab)
-        finally:
-            rt.lib.rt_scene_release(d)
-
-
 def test_seed_changes_image_and_is_reproducible(rt):
     from raytracing_c_amd.configs import load_config
     hs, _ = load_config("spheres")
