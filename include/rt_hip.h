@@ -64,8 +64,10 @@ extern RT_Device_Scene *rt_scene_upload(Scene const *scene);
 extern void             rt_scene_release(RT_Device_Scene *dscene);
 extern void             rt_scene_invalidate(Scene const *scene);
 /* render_thread_proc() re-reads, on every frame, the dimensions and base pointers of the host Scene, its material records
- * and the descriptors of the Images they reference (a few microseconds), and uploads again when any of that changed.  It
- * does NOT re-read the geometry or texel BYTES: a host that edits those in place calls rt_scene_invalidate().
+ * and the descriptors of the Images they reference in full, and a bounded sample of every block of geometry and texel bytes
+ * (blocks up to 4 KB in full, larger ones 8 runs of 512 bytes; tens of microseconds), and uploads again when any of that
+ * changed.  An in-place edit of a few vertices or texels inside a LARGE block can escape the sample: such a host calls
+ * rt_scene_invalidate().
  * rt_scene_verify() is the full comparison on demand: 1 = the cached copy still matches the host scene, 0 = it did not
  * (dropped; the next frame uploads), -1 = nothing cached for this Scene. */
 extern int              rt_scene_verify(Scene const *scene);

@@ -448,15 +448,17 @@ static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t
 // ---- stamps of a host Scene ---------------------------------------------------------------------------------
 // render_thread_proc / render / lightmap_bake keep one device copy per Scene* and must notice when the host scene
 // changed underneath it -- the reference reads the live Scene every frame.  Two levels:
-//  * scene_stamp(), paid on EVERY frame (a few microseconds): the dimensions and base pointers of the BVH and the
+//  * scene_stamp(), paid on EVERY frame (tens of microseconds): the dimensions and base pointers of the BVH and the
 //    triangle block, the background proc and Image, every distinct material record (PBR_Shader_Data, 80 bytes) and the
-//    descriptor (pointer, size, layout) of every Image a material references.  A rebuilt, reloaded or re-materialed
-//    scene, a changed material parameter and a swapped texture are all noticed.
-//  * What it does NOT read: the geometry bytes (nodes, coordinates, AoS records) and the texel bytes -- 5 MB + 50 MB for
-//    the helmet, 0.5 ms per frame even when sampled.  A host that edits those IN PLACE, keeping every pointer and size,
+//    descriptor (pointer, size, layout) of every Image a material references, IN FULL; of every block of geometry or texel
+//    bytes a bounded sample (hash_sampled: blocks up to 4 KB in full, larger ones 8 runs of 512 bytes).  A rebuilt,
+//    reloaded, regenerated or re-materialed scene, a changed material parameter, a swapped texture and any edit of a small
+//    scene are noticed.
+//  * What it can miss: an IN-PLACE edit of a few vertices or texels inside a large block (the helmet has 5 MB of geometry
+//    and 50 MB of texels; hashing them, even one word in 61, cost 0.5 ms per frame in round 2).  A host that does that
 //    calls rt_scene_invalidate(scene) afterwards; scene_init / scene_init_sah / scene_init_gpu /
-//    scene_load_bytes do that themselves.  scene_fingerprint() -- everything, texels of large images sampled -- is what
-//    rt_scene_verify() compares for a host that wants the check anyway.
+//    scene_load_bytes do so themselves.  scene_fingerprint() -- geometry in full, texels of large images one word in 61 --
+//    is what rt_scene_verify() compares for a host that wants the check anyway.
 static inline uint64_t mix64(uint64_t h, uint64_t v) {
   h ^= v;
   h *= 0x9E3779B97F4A7C15ull;
@@ -539,11 +541,31 @@ static uint64_t scene_fingerprint(Scene const *scene) {
 }
 
 
+// A bounded look at a block of bytes: blocks up to 4 KB in full, larger ones as 8 runs of 512 bytes spread evenly over the
+// block (runs, not single words: a run is 8 consecutive cache lines, a strided word per line would cost a miss each).
+static uint64_t hash_sampled(uint64_t h, const void *data, size_t n) {
+  if (!data || n == 0) return mix64(h, 0x5EEDu);
+  if (n <= 4096) return hash_bytes(h, data, n);
+  const unsigned char *b = (const unsigned char *)data;
+  const size_t run = 512, runs = 8, span = n - run;
+  for (size_t k = 0; k < runs; k++) {
+    size_t off = (span * k / (runs - 1)) & ~(size_t)7;
+    h = hash_bytes(h, b + off, run);
+  }
+  return mix64(h, (uint64_t)n);
+}
+
 static uint64_t hash_image_desc(uint64_t h, Image const *img) {
   if (!img) return mix64(h, 0x1234u);
   int64_t desc[6] = {(int64_t)img->components, (int64_t)img->pixel_type, (int64_t)img->width, (int64_t)img->stride,
                      (int64_t)img->height, (int64_t)(uintptr_t)img->pixels.data};
-  return hash_bytes(h, desc, sizeof desc);
+  h = hash_bytes(h, desc, sizeof desc);
+  if (img->pixels.data && img->pixel_type == PT_u8 && img->width > 0 && img->height > 0 && img->stride >= img->width &&
+      img->components > 0) {
+    size_t n = (size_t)img->stride * img->height * img->components;
+    if (img->pixels.len >= (isize)n) h = hash_sampled(h, img->pixels.data, n);
+  }
+  return h;
 }
 
 // `mat_ptrs` / `first_tri`: the distinct material records found at upload and one triangle that uses each.  A material
@@ -555,6 +577,15 @@ static uint64_t scene_stamp(Scene const *scene, const std::vector<const void *> 
                      (int64_t)(uintptr_t)scene->background.proc, (int64_t)(uintptr_t)scene->background.data,
                      (int64_t)(uintptr_t)scene->bvh.nodes.data, (int64_t)(uintptr_t)T.x[0], (int64_t)(uintptr_t)T.aos};
   uint64_t h = hash_bytes(0x452821E638D01377ull, head, sizeof head);
+  if (scene->bvh.nodes.data && scene->bvh.nodes.len > 0) h = hash_sampled(h, scene->bvh.nodes.data, (size_t)scene->bvh.nodes.len * sizeof(BVH_Node));
+  if (T.len > 0 && T.x[0] && T.aos) {
+    for (int k = 0; k < 3; k++) {
+      h = hash_sampled(h, T.x[k], (size_t)T.len * 4);
+      h = hash_sampled(h, T.y[k], (size_t)T.len * 4);
+      h = hash_sampled(h, T.z[k], (size_t)T.len * 4);
+    }
+    h = hash_sampled(h, T.aos, (size_t)T.len * sizeof(Triangle_AOS));
+  }
   if (T.aos)
     for (size_t k = 0; k < mat_ptrs.size(); k++) {
       const int32_t i = first_tri[k];

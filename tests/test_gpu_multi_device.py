@@ -83,13 +83,19 @@ def test_scene_stamp_notices_material_and_pointer_changes(rt, oracle):
     assert np.array_equal(b2["accum"], _oracle.render(hs, w, h, s, b)["accum"])
     assert not np.array_equal(b2["accum"], a["accum"])
     m.base_color.x = old
-    # a vertex moves in place: invisible to the stamp, seen by the full check, which drops the copy
-    x0 = T.x[0][0]
-    T.x[0][0] = x0 + 0.25
+    a2 = rt.render_frame(hs, w, h, s, b, want_accum=True)      # (the restored material is a change again: uploaded afresh)
+    assert np.array_equal(a2["accum"], a["accum"])
+    # ONE vertex in the middle of 4 800 triangles moves in place: outside the stamp's sample of the coordinate arrays,
+    # seen by the full check, which drops the copy
+    i = int(T.len) // 2 + 37
+    x0 = T.x[0][i]
+    T.x[0][i] = x0 + 0.25
+    stale = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(stale["accum"], a["accum"]), "documented: an in-place edit inside a large block needs rt_scene_invalidate"
     assert rt.lib.rt_scene_verify(C.byref(hs.scene)) == 0
     c = rt.render_frame(hs, w, h, s, b, want_accum=True)
     assert np.array_equal(c["accum"], _oracle.render(hs, w, h, s, b)["accum"])
-    T.x[0][0] = x0
+    T.x[0][i] = x0
     rt.lib.rt_scene_invalidate(C.byref(hs.scene))
     d = rt.render_frame(hs, w, h, s, b, want_accum=True)
     assert np.array_equal(d["accum"], a["accum"])
@@ -105,4 +111,4 @@ def test_frame_timing_is_reported(rt):
     t = abi.RT_Frame_Timing()
     assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0
     assert t.total_ms > 0 and t.gpu_path_ms > 0 and t.upload_ms == 0
-    assert t.stamp_ms < 0.5, "the per-frame scene check must stay in the microseconds"
+    assert t.stamp_ms < 0.2, "the per-frame scene check must stay in the microseconds"
