@@ -38,7 +38,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="helmet")
+    ap.add_argument("--config", default="helmet", choices=["spheres", "quad", "helmet", "tower", "helmet4k"],
+                    help="BASELINE.json configs[0..4]; the default is the configuration the metric is quoted on")
+    ap.add_argument("--pipeline", default="stream", choices=["stream", "wavefront"],
+                    help="stream = the product's path kernel; wavefront = the split camera / shade / trace pipeline (measurement only)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--samples", type=int, default=0)
@@ -49,6 +52,7 @@ def parse_args():
     ap.add_argument("--save", default="", help="write the last frame as PNG (rank 0)")
     ap.add_argument("--no-bvh-compare", action="store_true",
                     help="skip the side measurement of the opt-in SAH builder (config.bvh.sah)")
+    ap.add_argument("--dry-run-sleep", type=float, default=0.0, help=argparse.SUPPRESS)   # tests: ranks linger this long
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: ranks rendezvous (gloo), exchange an empty tile buffer, rank 0 prints a "
                          "stub line -- covers the launcher and the N-rank plumbing on a CPU-only machine")
@@ -68,19 +72,57 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through
     torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.
     This parent has not imported torch and never touches the GPU; it is not replaced by an exec, it waits
-    for the children and exits with their status."""
+    for the children and exits with their status.  The children run in a process group of their own: when the
+    parent is told to stop (SIGTERM from a `timeout`, the driver's time limit, Ctrl-C) or fails, the whole group --
+    torchrun and every rank, including one that hangs on the GPU -- is terminated, SIGKILLed after a grace period."""
+    import signal
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
-    line = None
-    for raw in proc.stdout:
-        txt = raw.decode("utf-8", "replace").rstrip("\n")
-        if txt.startswith("{") and line is None:
-            line = txt
-        else:
-            print(txt, file=sys.stderr)
-    rc = proc.wait()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, start_new_session=True)
+    pgid = proc.pid                                  # start_new_session: the child leads a new session and group
+
+    def group_alive():
+        try:
+            os.killpg(pgid, 0)
+            return True
+        except (ProcessLookupError, PermissionError):
+            return False
+
+    def kill_group(grace=float(os.environ.get("RT_BENCH_KILL_GRACE", "5"))):
+        for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 2.0)):
+            try:
+                os.killpg(pgid, sig)
+            except (ProcessLookupError, PermissionError):
+                return
+            t0 = time.time()
+            while time.time() - t0 < wait:
+                proc.poll()                          # reap torchrun so that the group can disappear
+                if not group_alive():
+                    return
+                time.sleep(0.05)
+
+    def on_signal(signum, _frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    line, rc = None, 1
+    try:
+        for raw in proc.stdout:
+            txt = raw.decode("utf-8", "replace").rstrip("\n")
+            if txt.startswith("{") and line is None:
+                line = txt
+            else:
+                print(txt, file=sys.stderr)
+        rc = proc.wait()
+    except KeyboardInterrupt as e:
+        print(f"bench.py: stopping the ranks ({e})", file=sys.stderr)
+        line, rc = None, 130
+    finally:
+        if proc.poll() is None or group_alive():
+            kill_group()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     if line is not None:
         print(line, flush=True)
     if rc == 0 and line is None:
@@ -153,8 +195,11 @@ def measured_profile(workload):
     """PMC summary of this workload (profiles/*_traffic.json, newest tag wins): HBM-side bytes, VALU
     wave-instructions, active lanes, SIMD cycles of ONE rt_path_kernel launch, collected by separate
     `rocprofv3 --pmc` passes of this same command (tools/profile_gpu.sh + tools/summarize_profile.py).
-    bench.py cannot read PMC counters itself: these values are REPLAYED and labelled as such."""
+    bench.py cannot read PMC counters itself: these values are REPLAYED and labelled as such -- and only while the
+    profile's `kernel_hash` (sources of the path kernel + compiler flags, raytracing_c_amd/buildinfo.py) equals the
+    tree's: returns (profile, file name, stale)."""
     import glob
+    from raytracing_c_amd.buildinfo import kernel_source_hash
     best = None
     # newest = last in name order (r01 < r01f < ... < r02): file times mean nothing after a fresh clone
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
@@ -164,7 +209,9 @@ def measured_profile(workload):
             continue
         if t.get("workload") == workload:
             best = (t, os.path.basename(f))
-    return best
+    if best is None:
+        return None
+    return best[0], best[1], best[0].get("kernel_hash") != kernel_source_hash()
 
 
 # MI355X: 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds its SIMD for 2 cycles (MI355X_MICROARCH.md,
@@ -176,19 +223,33 @@ VALU_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / 2.0 / 1e9      # G wave-instructions / 
 LDS_PEAK_GBS = 256 * 128 * MAX_CLOCK_HZ / 1e9           # 128 B / clk / CU
 
 
-def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_name):
-    """What binds rt_path_kernel is VALU issue (branchy fp32, scene resident in LDS / L2 / Infinity Cache), so the
-    headline fraction is VALU wave-instructions issued / issue slots.  The HBM figures are kept beside it: measured
-    HBM-side bytes (PMC) and SURVEY 8d's algorithmic scene bytes, which are served on chip and therefore are NOT
-    an HBM rate."""
+FP32_VECTOR_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz
+
+
+def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_name, kernel_ms_source, profile_scale=1.0):
+    """SURVEY 8d prices a ray at 200 flop per node visit + 480 per leaf visit.  The scene is cache resident (the 8d HBM byte
+    model gives a rate ABOVE the HBM peak: listed under `algorithmic`, labelled), and there is no dense contraction for
+    MFMA, so the roof this path can be priced against is the fp32 VECTOR peak -- `frac` = algorithmic flops / launch time /
+    157.3 TFLOP/s, computed LIVE from the in-kernel counters and the HIP-event launch time.  `decomposition` factors it:
+    VALU issue x active lanes x algorithmic flops per executed lane-instruction x 1/2 (no FMA contraction: one flop per
+    instruction against a 2-flop peak; bit parity with the CPU oracle forbids contraction).  Issue and lanes need PMC
+    counters: replayed from the newest committed profile of this workload, and only while its kernel hash matches the tree."""
     b_ray = tot.bytes_per_ray()
     ksec = kernel_ms * 1e-3 if kernel_ms and kernel_ms > 0 else None
     alg_bytes = rays_per_launch * b_ray
     rays = max(tot.rays, 1)
     node_bytes = 192.0 * tot.node_visits / rays * rays_per_launch
-    out = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": None,
+    flops_per_ray = (200.0 * tot.node_visits + 480.0 * tot.leaf_visits) / rays
+    flops = flops_per_ray * rays_per_launch
+    tflops = flops / ksec / 1e12 if ksec else None
+    out = {"bound": "fp32_vector", "achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": tflops / FP32_VECTOR_PEAK_TFLOPS if tflops else None,
            "traffic": None, "kernel": variant_name, "launches_averaged": int(n_launches), "kernel_ms": kernel_ms,
-           "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+           "kernel_ms_source": kernel_ms_source,
+           "flops": {"per_ray": flops_per_ray, "per_launch": flops,
+                     "model": "SURVEY 8d: 200 x node visits + 480 x leaf visits, counters from the kernel"},
+           "peak_note": "fp32 vector peak; MFMA does not apply (branchy fp32, no contraction), the HBM byte model of SURVEY 8d "
+                        "is served on chip (see algorithmic.ratio_to_hbm_peak)",
            "algorithmic": {"bytes_per_ray": b_ray, "bytes_per_launch": alg_bytes,
                            "rate_GBps": alg_bytes / ksec / 1e9 if ksec else None,
                            "ratio_to_hbm_peak": alg_bytes / ksec / 1e9 / HBM_PEAK_GBS if ksec else None,
@@ -204,29 +265,45 @@ def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_na
                      "rate_GBps": (alg_bytes - node_bytes) / ksec / 1e9 if ksec else None,
                      "note": "leaf tiles, shading records, texels through L1 / L2"}}
     if prof and ksec:
-        t, fname = prof
+        t, fname, stale = prof
         out["replayed_from"] = f"profiles/{fname}"
-        out["replayed_note"] = ("traffic, valu.* and hbm.* use PMC counters of one launch of this same workload and kernel "
-                                "(separate rocprofv3 --pmc passes, committed summary); only the launch time is live")
+        out["replayed_stale"] = bool(stale)
+        if stale:
+            out["replayed_note"] = ("the kernel sources or compiler flags changed since this profile was taken (kernel_hash "
+                                    "differs): its counters are NOT used; traffic, valu_issue and decomposition are null")
+            out["valu_issue"] = None
+            out["decomposition"] = None
+            return out
+        out["replayed_note"] = ("traffic, hbm.*, valu_issue.* and the issue / lanes factors of `decomposition` use PMC counters of "
+                                "one launch of this same workload and kernel (separate rocprofv3 --pmc passes, committed "
+                                "summary, kernel_hash equal to the tree's); launch time and flops are live")
+        if profile_scale != 1.0:
+            out["replayed_scaled"] = (f"counters of the single-GPU launch scaled by {profile_scale:.4f} = this rank's share of "
+                                      "the frame's rays")
         hbm = t.get("hbm_bytes_per_launch")
-        out["traffic"] = hbm
         if hbm:
+            hbm *= profile_scale
+            out["traffic"] = hbm
             out["hbm"] = {"achieved": hbm / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": hbm / ksec / 1e9 / HBM_PEAK_GBS, "traffic_over_algorithmic": hbm / alg_bytes,
                           "correction": t.get("correction")}
         v = t.get("valu") or {}
         if v.get("wave_insts"):
-            ach = v["wave_insts"] / ksec / 1e9
-            out["achieved"] = ach
-            out["frac"] = ach / VALU_PEAK_GINST
+            wi = v["wave_insts"] * profile_scale
+            ach = wi / ksec / 1e9
             lanes = v.get("active_lane_frac")
-            out["valu"] = {"wave_insts_per_launch": v["wave_insts"],
-                           "issue_frac_profiled_clock": v.get("issue_frac"),
-                           "active_lane_frac": lanes,
-                           "useful_lane_issue": (v.get("issue_frac") * lanes) if v.get("issue_frac") and lanes else None,
-                           "waves_per_simd": v.get("waves_per_simd"),
-                           "note": "issue_frac_profiled_clock = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): "
-                                   "issue slots at the clock of the profiled launch; useful = issue x active lanes"}
+            issue = ach / VALU_PEAK_GINST
+            out["valu_issue"] = {"achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": issue,
+                                 "wave_insts_per_launch": wi, "issue_frac_profiled_clock": v.get("issue_frac"),
+                                 "active_lane_frac": lanes, "waves_per_simd": v.get("waves_per_simd"),
+                                 "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction; "
+                                              "issue_frac_profiled_clock = the same at the clock of the profiled launch"}
+            if lanes:
+                per_lane_inst = flops / (wi * 64.0 * lanes)
+                out["decomposition"] = {"valu_issue": issue, "active_lanes": lanes,
+                                        "flops_per_executed_lane_instruction": per_lane_inst, "fma_factor": 0.5,
+                                        "product": issue * lanes * per_lane_inst * 0.5,
+                                        "note": "product = frac (up to the ratio of the nominal 2.4 GHz to itself): every factor is a lever"}
     return out
 
 
@@ -284,6 +361,9 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.init_process_group("gloo")
     part = FramePartition(args.width or 1920, args.height or 1080, world)
+    if args.dry_run_sleep > 0:
+        print(f"rank {rank} pid {os.getpid()} sleeping", file=sys.stderr, flush=True)
+        time.sleep(args.dry_run_sleep)
     tiles = torch.full((part.max_local, 1024 * 3), rank, dtype=torch.uint8)
     t0 = time.perf_counter()
     got = gather_tiles(tiles, world, rank) if world > 1 else tiles[None]
@@ -340,6 +420,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if rt.lib.rt_init(local_rank) != 0:
         raise RuntimeError("rt_init: " + rt.last_error())
+    if args.pipeline == "wavefront":
+        rt.lib.rt_set_pipeline(1)
     dist = None
     force_dist = world == 1 and os.environ.get("RT_BENCH_FORCE_DIST") == "1"     # rehearsal: RCCL path with one rank
     if force_dist:
@@ -476,6 +558,18 @@ def main():
     # stream around every launch) and the in-kernel counters of the last frame
     n_launches = C.c_int32(0)
     last_ms = float(rt.lib.rt_kernel_timing_mean_ms(C.byref(n_launches)))
+    kernel_ms_source = "HIP events around every launch of the timed region"
+    if overlap:
+        # with consecutive frames' kernels on two streams an event interval also holds the time the OTHER frame's kernel kept
+        # the CUs: the per-launch time the roofline uses comes from two launches on one stream after the timed region
+        rt.lib.rt_kernel_timing_reset()
+        for _ in range(2):
+            accums[0].zero_()
+            if rt.lib.rt_render_accumulate(dscenes[0], C.byref(params), accums[0].data_ptr(), torch.cuda.current_stream().cuda_stream) != 0:
+                raise RuntimeError(rt.last_error())
+            torch.cuda.synchronize()
+        last_ms = float(rt.lib.rt_kernel_timing_mean_ms(C.byref(n_launches)))
+        kernel_ms_source = "2 launches on ONE stream after the timed region (the timed region overlaps consecutive frames' kernels)"
     cnt = rt.render.get_counters()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     stats = torch.tensor([cnt.paths, cnt.rays, cnt.node_visits, cnt.leaf_visits, cnt.shades, cnt.backgrounds,
@@ -499,19 +593,22 @@ def main():
         # the chunks, the slowest rank's time is used.
         rays_per_launch = rays / world
         workload = f"{cfg['asset']} {w}x{h}, {s} spp, {b} bounces"
-        if args.config == "helmet" and (w, h, s, b) == (1920, 1080, 256, 8):
-            workload += " (BASELINE.json configs[2])"
-        elif args.config == "helmet4k" and (w, h, s, b) == (3840, 2160, 1024, 16):
-            workload += " (BASELINE.json configs[4])"
-        prof = measured_profile(workload) if world == 1 else None
-        variant = os.environ.get("RT_KERNEL", "5 = rt_path_kernel_stream<16, true, 1, short reciprocal>, the default")
+        from raytracing_c_amd.configs import CONFIGS
+        names = ["spheres", "quad", "helmet", "tower", "helmet4k"]
+        if args.config in names and tuple(CONFIGS[args.config][1:5]) == (w, h, s, b):
+            workload += f" (BASELINE.json configs[{names.index(args.config)}])"
+        prof = measured_profile(workload)
+        pipeline = "wavefront pipeline (rt_wf_camera / shade / trace kernels)" if rt.lib.rt_get_pipeline() == 1 else \
+            "rt_path_kernel_stream<16, true, 1, short reciprocal> (the product's one path kernel)"
+        if prof is not None and rt.lib.rt_get_pipeline() == 1:
+            prof = None                                 # the committed profiles are of the tile-stream kernel
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "scene": "assets/helmet.glb = self-contained models/helmet.gltf; procedural 2048x1024 "
-                                "equirect background (background.png is a missing blob); seed 0x1234ABCD",
+                       "scene": f"assets/{cfg['asset']}" + (" = self-contained models/helmet.gltf" if "helmet" in cfg["asset"] else "")
+                                + "; procedural 2048x1024 equirect background (background.png is a missing blob); seed 0x1234ABCD",
                        "bvh": {"headline": "scene_init (the reference's fixed-capacity split, scene.c:311-414)",
                                "reference": {"mray_per_s": mrays, "node_visits_per_ray": tot.node_visits / max(rays, 1),
                                              "leaf_visits_per_ray": tot.leaf_visits / max(rays, 1),
@@ -528,8 +625,9 @@ def main():
             "leaf_visits_per_ray": tot.leaf_visits / max(rays, 1),
             "shades_per_ray": tot.shades / max(rays, 1),
             "kernel_ms": last_ms,
-            "roofline": roofline_block(tot, rays_per_launch, last_ms, n_launches.value, prof,
-                                       f"rt_path_kernel (RT_KERNEL={variant})"),
+            "roofline": roofline_block(tot, rays_per_launch, last_ms, n_launches.value, prof, pipeline, kernel_ms_source,
+                                       profile_scale=(rays_per_launch / prof[0]["rays_per_launch"])
+                                       if prof and world > 1 and prof[0].get("rays_per_launch") else 1.0),
         }
         if world == 1 and not args.no_bvh_compare:
             out["config"]["bvh"]["sah"] = bvh_compare(rt, abi, args, cfg, host_images[(frame_no[0] - 1) & 1].numpy())

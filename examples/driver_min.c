@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "rt_hip.h"
@@ -150,10 +151,30 @@ static int render_and_write(Scene *scene_p, int width, int height, int samples, 
   Rendering_Context ctx = { .image = image, .scene = &scene, .max_bounces = bounces, .n_threads = n_threads,       /* driver.c:793-799 */
                             .samples = samples };
   pthread_t th[64];
-  for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, thread_main, &ctx);                              /* driver.c:801-803 */
-  while (!rendering_context_is_finished(&ctx)) usleep(1000);                                                       /* driver.c:810-818 */
-  for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
-  if (rt_last_error()[0]) { fprintf(stderr, "driver_min: render failed: %s\n", rt_last_error()); return 2; }
+  /* DRIVER_MIN_FRAMES=n renders the frame n times (the context re-armed each time) and prints where the time of every frame
+   * went -- the reference's `-V` prints render ms and samples/second (driver.c:821-825); rt_get_frame_timing() splits it. */
+  int frames = getenv("DRIVER_MIN_FRAMES") ? atoi(getenv("DRIVER_MIN_FRAMES")) : 1;
+  if (frames < 1) frames = 1;
+  for (int f = 0; f < frames; f++) {
+    ctx.n_threads = n_threads;
+    ctx._current_chunk = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, thread_main, &ctx);                            /* driver.c:801-803 */
+    while (!rendering_context_is_finished(&ctx)) usleep(frames > 1 ? 20 : 1000);                                   /* driver.c:810-818 */
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    if (rt_last_error()[0]) { fprintf(stderr, "driver_min: render failed: %s\n", rt_last_error()); return 2; }
+    if (frames > 1) {
+      RT_Frame_Timing ft;
+      rt_get_frame_timing(&ft);
+      double wall = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+      printf("driver_min: frame %d: host wall %.3f ms (%.1f Msample/s) | library total %.3f = stamp %.3f + upload %.3f + enqueue %.3f ... | "
+             "gpu: clear+prepare %.3f, path kernel %.3f, resolve %.3f, copy to host %.3f\n", f, wall,
+             (double)width * height * samples / wall / 1e3, ft.total_ms, ft.stamp_ms, ft.upload_ms, ft.enqueue_ms, ft.gpu_prep_ms,
+             ft.gpu_path_ms, ft.gpu_resolve_ms, ft.gpu_copy_ms);
+    }
+  }
 
   if (denoise) {                                                                                                   /* driver.c:827-837 */
     Image denoised = image;

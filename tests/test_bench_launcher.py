@@ -39,6 +39,56 @@ def test_bench_launcher_relays_failure_status():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_stopping_the_launcher_stops_every_rank():
+    """the parent is killed (a `timeout`, the driver's limit, Ctrl-C) exactly when a rank hangs.  The ranks run in
+    a process group of their own; SIGTERM to the parent must take torchrun and every rank down with it."""
+    import re
+    import signal
+    import time
+    e = dict(os.environ, RT_BENCH_KILL_GRACE="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--dry-run-sleep", "120"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, cwd=ROOT)
+    pids, t0 = [], time.time()
+    os.set_blocking(p.stderr.fileno(), False)
+    buf = ""
+    while len(pids) < 2 and time.time() - t0 < 120:
+        try:
+            buf += os.read(p.stderr.fileno(), 65536).decode("utf-8", "replace")
+        except BlockingIOError:
+            pass
+        pids = [int(m) for m in re.findall(r"rank \d+ pid (\d+) sleeping", buf)]
+        if p.poll() is not None:
+            break
+        time.sleep(0.1)
+    assert len(pids) == 2, buf[-2000:]
+    p.send_signal(signal.SIGTERM)
+    try:
+        rc = p.wait(timeout=30)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert rc != 0
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        try:                                           # a zombie waiting for its (dead) parent's reaper is not a survivor
+            return open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    t0 = time.time()
+    while any(alive(x) for x in pids) and time.time() - t0 < 10:
+        time.sleep(0.1)
+    assert not [x for x in pids if alive(x)], "ranks survived the launcher"
+
+
 @pytest.mark.gpu
 def test_bench_distributed_pipeline_on_one_gpu(tmp_path):
     """The N > 1 frame pipeline of bench.py -- path kernels of consecutive frames on two streams with a device scene each,

@@ -1,20 +1,41 @@
 #!/usr/bin/env python3
-"""Renders the five BASELINE.json configurations on ONE MI355X and prints a markdown table
-(kernel time from HIP events, rays counted in-kernel).  Output committed as profiles/<tag>_configs.md."""
+"""The five BASELINE.json configurations on ONE MI355X, GPU beside CPU: kernel time from HIP events
+and rays counted in-kernel for the GPU; for the CPU the oracle (the repo's CPU restatement of the reference path, rebuilt
+-O3 -march=native on this host) with all host threads and with one -- configs #4 / #5 at samples / 16, stated in the table,
+as BASELINE.md allows.  Prints markdown, committed as profiles/<tag>_configs.md.
+    python tools/run_configs.py [--no-cpu]"""
 import ctypes as C
 import os
+import subprocess
 import sys
+import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch                                           # noqa: E402
 import raytracing_c_amd as rt                          # noqa: E402
 from raytracing_c_amd import ctypes_abi as abi         # noqa: E402
-from raytracing_c_amd.configs import CONFIGS, load_config   # noqa: E402
+from raytracing_c_amd.configs import load_config       # noqa: E402
+from tests import _oracle                              # noqa: E402
 
 assert rt.lib.rt_init(0) == 0
-print("| config | scene | frame | kernel ms (mean of 3, after 1 warm-up) | Mray/s | Msample/s | rays/path | nodes/ray | leaves/ray | shades/ray | B/ray |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+cpu = "--no-cpu" not in sys.argv
+cores = len(os.sched_getaffinity(0))
+try:
+    q = open("/sys/fs/cgroup/cpu.max").read().split()
+    if q[0] != "max":
+        cores = max(1, min(cores, int(round(int(q[0]) / int(q[1])))))
+except Exception:
+    pass
+lib = None
+if cpu:
+    out = os.path.join(tempfile.mkdtemp(prefix="oracle_native_"), "liboracle_native.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "MARCH=native", f"OUT={out}"], stdout=subprocess.DEVNULL)
+    lib = _oracle.load(out)
+print(f"| config | scene | frame | GPU kernel ms (mean of 3 after 1 warm-up) | GPU Mray/s | GPU Msample/s | CPU sample | CPU s ({cores} threads) | "
+      f"CPU Mray/s ({cores} threads) | CPU Msample/s | CPU Mray/s (1 thread) | GPU / CPU | rays/path | nodes/ray | leaves/ray | shades/ray | B/ray |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for i, name in enumerate(["spheres", "quad", "helmet", "tower", "helmet4k"]):
     hs, cfg = load_config(name)
     w, h, s, b = cfg["width"], cfg["height"], cfg["samples"], cfg["max_bounces"]
@@ -29,7 +50,23 @@ for i, name in enumerate(["spheres", "quad", "helmet", "tower", "helmet4k"]):
     torch.cuda.synchronize()
     ms = rt.lib.rt_kernel_timing_mean_ms(None)
     c = rt.render.get_counters()
-    print(f"| #{i + 1} | {cfg['asset']} | {w}x{h}, {s} spp, {b} bounces | {ms:.3f} | {c.rays / ms / 1e3:.0f} | {w * h * s / ms / 1e3:.0f} | "
-          f"{c.rays / c.paths:.3f} | {c.node_visits / c.rays:.3f} | {c.leaf_visits / c.rays:.3f} | {c.shades / c.rays:.3f} | {c.bytes_per_ray():.0f} |", flush=True)
     rt.lib.rt_scene_release(d)
     del accum
+    cpu_cols = "| - | - | - | - | - | - "
+    if cpu:
+        cs = s if i < 3 else max(1, s // 16)            # #4 / #5 at spp / 16, scaled linearly
+        t0 = time.perf_counter()
+        r = _oracle.render(hs, w, h, cs, b, n_threads=cores, lib=lib)
+        dt = time.perf_counter() - t0
+        one_s = max(1, min(cs, int(round(cs * 3.0 / max(dt * cores, 1e-3)))))      # about three seconds on one thread
+        t0 = time.perf_counter()
+        r1 = _oracle.render(hs, w, h, one_s, b, n_threads=1, lib=lib)
+        dt1 = time.perf_counter() - t0
+        mr = r["counters"]["rays"] / dt / 1e6
+        cpu_cols = (f"| {cs} of {s} spp | {dt:.2f} | {mr:.1f} | {w * h * cs / dt / 1e6:.1f} | {r1['counters']['rays'] / dt1 / 1e6:.2f} ({one_s} spp) | "
+                    f"{c.rays / ms / 1e3 / mr:.0f}x ")
+    print(f"| #{i + 1} | {cfg['asset']} | {w}x{h}, {s} spp, {b} bounces | {ms:.3f} | {c.rays / ms / 1e3:.0f} | {w * h * s / ms / 1e3:.0f} "
+          f"{cpu_cols}| {c.rays / c.paths:.3f} | {c.node_visits / c.rays:.3f} | {c.leaf_visits / c.rays:.3f} | {c.shades / c.rays:.3f} | "
+          f"{c.bytes_per_ray():.0f} |", flush=True)
+print(f"\nCPU = oracle/oracle.c (kind \"port\": the reference cannot be built here), gcc -O3 -march=native, {cores} host threads of the GPU box; "
+      "GPU / CPU compares Mray/s at equal work per sample (a reported baseline, not a target).")

@@ -62,7 +62,9 @@ def main(tag):
         # MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads half
         # the bytes of 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
         hbm = (2.0 * fetch_kb + write_kb) * 1024.0
-        traffic = {"tag": tag, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "hbm_bytes_per_launch": hbm,
+        sys.path.insert(0, ROOT)
+        from raytracing_c_amd.buildinfo import hipflags, kernel_source_hash
+        traffic = {"tag": tag, "kernel_hash": kernel_source_hash(), "hipflags": hipflags(), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "hbm_bytes_per_launch": hbm,
                    "correction": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane reads) + WRITE_SIZE, x 1024",
                    "workload": bench["config"]["workload"] if bench else None,
                    "rays_per_launch": bench["rays_per_frame"] if bench else None}
