@@ -1818,6 +1818,17 @@ extern "C" int scene_init_gpu(Scene *scene, Triangle_Slice src, Allocator alloca
   }
   if (src.len < 0 || (src.len > 0 && !src.data)) return rt_fail("scene_init_gpu: bad triangle slice");
   if (src.len > (isize)1 << 27) return rt_fail("scene_init_gpu: %ld triangles are too many", (long)src.len);
+  // The GPU build orders centroid keys with a radix sort of their bit patterns, which equals the `<` order of scene_init's
+  // merge sort for every number including the infinities -- but not for NaN (`<` leaves a NaN where it stands, the radix
+  // order puts it behind +inf).  A soup with a NaN coordinate is therefore built by scene_init itself: same Scene by definition.
+  for (isize i = 0; i < src.len; i++)
+    for (int v = 0; v < 3; v++) {
+      const Vec3 &q = src.data[i].positions[v];
+      if (q.x != q.x || q.y != q.y || q.z != q.z) {
+        scene_init(scene, src, allocator);
+        return 0;
+      }
+    }
   if (!rt_scene_alloc(scene, src.len, allocator)) return rt_fail("scene_init_gpu: the allocator failed");   // (drops a stale device copy)
   char err[256] = "";
   std::lock_guard<std::mutex> lock(D.mutex);

@@ -298,6 +298,7 @@ extern "C" int rt_gpu_build(const Triangle *h_tris, long n_in, long depth, BVH_N
     if (need > tmp_bytes) {
       if (tmp) (void)hipFree(tmp);
       tmp = nullptr;
+      b_tmp.p = nullptr;              // (b_tmp's destructor must not free the old block a second time if the hipMalloc below fails)
       tmp_bytes = 0;
       e = hipMalloc(&tmp, need);
       if (e != hipSuccess) return e;

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
               if (phase == PH_NEED && rank < back) {
                 const uint32_t *q = pk + (n_parked - 1 - rank);         // most recently parked first
                 uint32_t v[RT_PARK_FIELDS];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int i = 0; i < RT_PARK_FIELDS; i++)
                   v[i] = __hip_atomic_load(q + i * RT_PARK_CAP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -340,6 +341,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                                                   rng, (uint32_t)pix | ((uint32_t)bounce << 6)};
 #pragma unroll
               for (int i = 0; i < RT_PARK_FIELDS; i++) q[i * RT_PARK_CAP] = v[i];
+              // the record is read back by ANOTHER lane of this wave (agent-scope loads below): the release / acquire pair at
+              // wavefront scope states that order to the compiler; the hardware returns one wave's vector memory operations in order
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               phase = PH_NEED;
             }
             n_parked += h;

@@ -455,10 +455,15 @@ static void sah_build(Scene *scene, Triangle *tris, isize count, isize depth, BV
       if (pos > 0 && cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = pos; }
     }
     f32 whole = s->area * sah_w(s->len);
-    if (best_axis < 0 || (!forced && !(best_cost < whole))) {
-      /* (a forced slice always has a feasible cut: the invariant sum ceil(len / capacity) <= 8 holds) */
+    if (forced && best_axis < 0) {
+      /* A slice that MUST be cut has a feasible position (the invariant sum ceil(len / capacity) <= 8 holds), but the sweep
+       * accepts only finite costs: a vertex at +-inf, or coordinates around 1e20 whose surface area overflows, leave every
+       * candidate at inf or NaN.  Cut by count then, as the reference's split does (scene.c:333-380): a multiple of the child
+       * capacity keeps the slot budget, and no triangle is dropped. */
+      best_axis = 2;                                   /* (the order the last sort left) */
+      best_pos = capacity * (ceil_div(s->len, capacity) / 2);
+    } else if (best_axis < 0 || (!forced && !(best_cost < whole))) {
       s->final = true;
-      if (forced) break;                               /* unreachable; guards against an endless loop */
       continue;
     }
     if (best_axis != 2) sort_triangle_slice(s->data, s->len, best_axis, &sb->sb);

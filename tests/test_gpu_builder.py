@@ -87,3 +87,31 @@ def test_scene_built_on_the_gpu_renders_like_the_oracle(oracle):
     got = rt.render_frame(hs, 96, 54, 4, 6, want_accum=True)
     assert np.array_equal(want["accum"], got["accum"])
     print(f"scene_init_gpu: {hs.scene_init_seconds * 1e3:.2f} ms for {hs.n_input_triangles} triangles")
+
+
+@pytest.mark.gpu
+def test_nan_vertex_falls_back_to_the_cpu_split():
+    """the radix order of the GPU build differs from scene_init's `<` order only for NaN keys; a soup with a NaN
+    coordinate is built by scene_init itself, so scene_init_gpu still returns the same Scene byte for byte."""
+    import raytracing_c_amd as rt
+    from raytracing_c_amd import ctypes_abi as abi
+    assert rt.lib.rt_init(0) == 0, rt.last_error()
+    rng = np.random.default_rng(12)
+    n = 300
+    tri = np.zeros(n, abi.TRIANGLE_DTYPE)
+    tri["positions"] = (rng.uniform(-1, 1, (n, 1, 3)) + rng.normal(size=(n, 3, 3)) * 0.1).astype(np.float32)
+    tri["positions"][41, 2, 1] = np.nan
+    tri["normals"] = np.tile(np.array([0, 0, 1], np.float32), (n, 3, 1))
+    tri["shader_proc"] = rt.native.symbol_address("disney_shader_proc")
+    out = []
+    for fn in (rt.lib.scene_init, rt.lib.scene_init_gpu):
+        sc = abi.Scene()
+        fn(C.byref(sc), abi.Triangle_Slice(tri.ctypes.data, n), abi.Allocator())
+        nn = int(sc.bvh.nodes.len)
+        nodes = np.ctypeslib.as_array(C.cast(sc.bvh.nodes.data, C.POINTER(C.c_float)), (nn * 48,)).copy()
+        coords = np.ctypeslib.as_array(sc.triangles.x[0], (int(sc.triangles.len) * 9,)).copy()
+        out.append((nodes, coords, int(sc.bvh.depth)))
+        rt.lib.rt_scene_free(C.byref(sc))
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
