@@ -45,6 +45,8 @@ def main():
         for label, env in arms:
             saved = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
+            # (the product library reads no experiment knob from the environment: the pipeline is chosen through the API)
+            rt.lib.rt_set_pipeline(1 if os.environ.get("RT_PIPELINE") == "wf" else 0)
             full = run(0, 1, reps)
             digest = hashlib.sha256(accum.cpu().numpy().tobytes()).hexdigest()[:12]
             c = rt.render.get_counters()
