@@ -229,6 +229,10 @@ extern int rt_test_trace(RT_Device_Scene *dscene, i32 n, f32 const *rays,
 extern int rt_test_trace_stream(RT_Device_Scene *dscene, i32 n, f32 const *rays, f32 const *pyramid, i32 exit_lanes, i32 mode,
                                 f32 *out_t, i32 *out_tri, f32 *out_uv, u64 visits[2]);
 
+/* The visiting order the per-launch preparation kernel derives from per-tile costs (rays a tile needed in the previous
+ * launch of the same view): order[0 .. n_tiles) = a permutation of the tiles, most expensive cost bucket first. */
+extern int rt_test_tile_order(i32 n_tiles, u32 const *cost, u32 *order);
+
 /* Bilinear fetch (driver.c:49-93) of n (u,v) pairs on texture `tex` of the
  * uploaded scene (index in upload order; -1 = background image). */
 extern int rt_test_texture(RT_Device_Scene *dscene, i32 tex, i32 n, f32 const *uv, f32 *out_rgb);

@@ -1937,6 +1937,29 @@ extern "C" int rt_test_srgb_sweep(u64 out[3]) { return run_sweep(rt_launch_test_
 // patterns: out[0] differing patterns (0 expected), out[1] first differing pattern + 1.
 extern "C" int rt_test_quantize_sweep(u64 out[2]) { return run_sweep(rt_launch_test_quantize_sweep, "rt_test_quantize_sweep", out, 2); }
 
+// The tile order the preparation kernel derives from per-tile costs (rays of the previous launch): order[] must be a
+// permutation of 0 .. n_tiles - 1 with non-increasing cost buckets (rt_kernels.hip: cost_bucket, 4 per power of two).
+extern "C" int rt_test_tile_order(i32 n_tiles, u32 const *cost, u32 *order) {
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0) return -1;
+  if (n_tiles <= 0 || !cost || !order) return rt_fail("rt_test_tile_order: bad arguments");
+  DevBuf bc, bo, bn, bk, bw, bz;
+  HIP_TRY(bc.alloc((size_t)n_tiles * 4));
+  HIP_TRY(bo.alloc((size_t)n_tiles * 4));
+  HIP_TRY(bn.alloc(((size_t)n_tiles + (size_t)(n_tiles + 63) / 64) * 4));
+  HIP_TRY(bk.alloc(RT_N_COUNTERS * 8));
+  HIP_TRY(bw.alloc(64));
+  HIP_TRY(bz.alloc((size_t)n_tiles * 4));
+  HIP_TRY(hipMemcpy(bc.p, cost, (size_t)n_tiles * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(bo.p, 0xFF, (size_t)n_tiles * 4));
+  int rc = rt_launch_prepare(n_tiles, bn.as<uint32_t>(), bn.as<uint32_t>() + n_tiles, bk.as<unsigned long long>(), bw.as<uint32_t>(),
+                             bz.as<uint32_t>(), bc.as<uint32_t>(), bo.as<uint32_t>(), nullptr);
+  if (rc == 0) rc = (int)hipMemcpy(order, bo.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost);
+  if (rc != 0) return rt_fail("rt_test_tile_order failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
 static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
   memset(K, 0, sizeof *K);
   K->nodes = d->nodes;

@@ -154,7 +154,7 @@ EXPORTED_SYMBOLS = [
     # rt_hip.h
     "rt_last_error", "rt_clear_error", "rt_init", "rt_set_seed", "rt_get_seed",
     "rt_set_devices", "rt_device_count", "rt_set_pipeline", "rt_get_pipeline", "rt_set_wavefront_capacity",
-    "rt_scene_verify", "rt_get_frame_timing", "rt_test_trace_stream",
+    "rt_scene_verify", "rt_get_frame_timing", "rt_test_trace_stream", "rt_test_tile_order",
     "rt_scene_upload", "rt_scene_release", "rt_scene_invalidate", "rt_scene_device_bytes", "rt_set_camera",
     "rt_chunk_count", "rt_chunk_owner", "rt_local_chunk_count", "rt_max_local_chunk_count", "rt_local_chunk_list", "rt_render_accumulate", "rt_resolve", "rt_untile",
     "rt_denoise", "rt_render_frame", "rt_get_counters", "rt_get_sched_stats", "rt_get_wave_times", "rt_last_kernel_ms", "rt_kernel_timing_reset", "rt_kernel_timing_mean_ms",

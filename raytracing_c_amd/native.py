@@ -126,6 +126,7 @@ def _declare(d):
     d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     d.rt_test_trace_stream.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    d.rt_test_tile_order.argtypes = [C.c_int32, vp, vp]
     d.rt_set_devices.argtypes = [C.c_int32, C.c_int32]
     d.rt_device_count.restype = C.c_int32
     d.rt_set_pipeline.argtypes = [C.c_int32]

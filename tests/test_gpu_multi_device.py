@@ -112,3 +112,23 @@ def test_frame_timing_is_reported(rt):
     assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0
     assert t.total_ms > 0 and t.gpu_path_ms > 0 and t.upload_ms == 0
     assert t.stamp_ms < 0.2, "the per-frame scene check must stay in the microseconds"
+
+
+@pytest.mark.parametrize("n_tiles", [1, 63, 64, 1000, 16384, 32400, 130560])
+def test_preparation_kernel_orders_tiles_by_cost(rt, n_tiles):
+    """One launch replaces round 2's three memsets and five small kernels per frame; its counting sort (per-wave counts,
+    no contended atomic) must hand out every tile exactly once, most expensive cost bucket first."""
+    rng = np.random.default_rng(n_tiles)
+    cost = (rng.lognormal(6, 2.5, n_tiles)).astype(np.uint32)
+    cost[rng.random(n_tiles) < 0.3] = 0
+    cost[: n_tiles // 3] = 4096                                  # a big bucket, as the sky tiles of a frame are
+    order = np.zeros(n_tiles, np.uint32)
+    assert rt.lib.rt_test_tile_order(n_tiles, cost.ctypes.data, order.ctypes.data) == 0, rt.last_error()
+    assert np.array_equal(np.sort(order), np.arange(n_tiles, dtype=np.uint32))
+
+    def bucket(c):
+        c = c.astype(np.int64)
+        e = np.floor(np.log2(np.maximum(c, 1))).astype(np.int64)
+        return np.where(c < 4, c, 4 * (e - 1) + ((c >> np.maximum(e - 2, 0)) & 3))
+    b = bucket(cost[order])
+    assert (np.diff(b) <= 0).all()
