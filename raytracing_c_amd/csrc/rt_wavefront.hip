@@ -792,19 +792,28 @@ static int wf_set_lds(K kernel, int smem_bytes) {
     }                                                                                                                    \
   } while (0)
 
+// (geometries 1 and 2 were measured slower, profiles/r03_experiments.md: they exist in the diagnostic build only)
 extern "C" int rt_wf_launch_camera(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream) {
   int rc;
+#ifdef RT_DIAG_VARIANTS
   if (geometry == 1) WF_LAUNCH(rt_wf_camera_kernel, 12, 6);
   else if (geometry == 2) WF_LAUNCH(rt_wf_camera_kernel, 10, 5);
-  else WF_LAUNCH(rt_wf_camera_kernel, 16, 4);
+  else
+#endif
+  WF_LAUNCH(rt_wf_camera_kernel, 16, 4);
+  (void)geometry;
   return (int)hipGetLastError();
 }
 
 extern "C" int rt_wf_launch_trace(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream) {
   int rc;
+#ifdef RT_DIAG_VARIANTS
   if (geometry == 1) WF_LAUNCH(rt_wf_trace_kernel, 12, 6);
   else if (geometry == 2) WF_LAUNCH(rt_wf_trace_kernel, 10, 5);
-  else WF_LAUNCH(rt_wf_trace_kernel, 16, 4);
+  else
+#endif
+  WF_LAUNCH(rt_wf_trace_kernel, 16, 4);
+  (void)geometry;
   return (int)hipGetLastError();
 }
 
