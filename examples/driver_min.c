@@ -3,7 +3,7 @@
  * render_thread_proc, poll rendering_context_is_finished, optionally denoise, write the image.
  *
  *   make -C examples        (cc -std=gnu11 ... driver_min.c rt_model.c -lrt_hip -lpthread -lm)
- *   examples/driver_min MODEL W H SAMPLES BOUNCES THREADS out.ppm [-D] [--background bg.rgb8] [--camera "tx ty tz qx qy qz qw fov"]
+ *   examples/driver_min MODEL W H SAMPLES BOUNCES THREADS out.ppm|out.png|out.qoi [-D] [--background bg.rgb8] [--camera "tx ty tz qx qy qz qw fov"]
  *
  * MODEL is a model file as in driver.c:685-728 -- `.obj`, `.glb`, `.gltf`, loaded by rt_model.c (textures and the
  * environment map from RT8I side files, tools/extract_textures.py) -- or a `.rtscene` dump of what the loaders produce
@@ -36,6 +36,106 @@ static int die(char const *msg) {
 }
 
 static int render_and_write(Scene *scene, int width, int height, int samples, int bounces, int n_threads, int denoise, char const *out_path);
+
+/* ---- image writers, chosen by the suffix of the output path as in driver.c:839-877 (png_save_writer / qoi_save_writer /
+ * ppm_save_writer are codin functions there; these are self-contained) ------------------------------------------------ */
+static unsigned crc32_update(unsigned c, unsigned char const *p, size_t n) {
+  static unsigned table[256];
+  if (!table[1]) for (unsigned i = 0; i < 256; i++) { unsigned k = i; for (int j = 0; j < 8; j++) k = (k & 1) ? 0xEDB88320u ^ (k >> 1) : k >> 1; table[i] = k; }
+  c = ~c;
+  for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return ~c;
+}
+static void put_be32(unsigned char *p, unsigned v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+static int png_chunk(FILE *o, char const *type, unsigned char const *data, size_t n) {
+  unsigned char hd[8], tail[4];
+  put_be32(hd, (unsigned)n);
+  memcpy(hd + 4, type, 4);
+  unsigned c = crc32_update(0, hd + 4, 4);
+  if (n) c = crc32_update(c, data, n);
+  put_be32(tail, c);
+  return fwrite(hd, 1, 8, o) == 8 && (!n || fwrite(data, 1, n, o) == n) && fwrite(tail, 1, 4, o) == 4;
+}
+/* 8-bit RGB PNG, filter 0 on every row, zlib stream of STORED deflate blocks (valid PNG, no compression) */
+static int write_png(FILE *o, unsigned char const *rgb, int w, int h) {
+  static unsigned char const sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  unsigned char ihdr[13];
+  put_be32(ihdr, (unsigned)w); put_be32(ihdr + 4, (unsigned)h);
+  ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  size_t row = (size_t)w * 3 + 1, raw = row * (size_t)h, n_blocks = (raw + 65534) / 65535;
+  size_t zlen = 2 + raw + 5 * n_blocks + 4;
+  unsigned char *z = malloc(zlen), *q = z;
+  if (!z) return 0;
+  *q++ = 0x78; *q++ = 0x01;
+  unsigned a = 1, b = 0;                                   /* Adler-32 of the filtered scanlines */
+  size_t pos = 0;
+  for (size_t blk = 0; blk < n_blocks; blk++) {
+    size_t len = raw - pos < 65535 ? raw - pos : 65535;
+    *q++ = blk + 1 == n_blocks; *q++ = len & 0xFF; *q++ = len >> 8; *q++ = ~len & 0xFF; *q++ = (~len >> 8) & 0xFF;
+    for (size_t i = 0; i < len; i++, pos++) {
+      size_t y = pos / row, x = pos % row;
+      unsigned char v = x ? rgb[y * (size_t)w * 3 + x - 1] : 0;
+      *q++ = v;
+      a = (a + v) % 65521; b = (b + a) % 65521;
+    }
+  }
+  put_be32(q, (b << 16) | a);
+  int ok = fwrite(sig, 1, 8, o) == 8 && png_chunk(o, "IHDR", ihdr, 13) && png_chunk(o, "IDAT", z, zlen) && png_chunk(o, "IEND", NULL, 0);
+  free(z);
+  return ok;
+}
+/* QOI (qoiformat.org), 3 channels, sRGB */
+static int write_qoi(FILE *o, unsigned char const *rgb, int w, int h) {
+  unsigned char hd[14] = {'q', 'o', 'i', 'f'};
+  put_be32(hd + 4, (unsigned)w); put_be32(hd + 8, (unsigned)h); hd[12] = 3; hd[13] = 0;
+  size_t n = (size_t)w * h;
+  unsigned char *buf = malloc(n * 4 + 8), *q = buf;
+  if (!buf) return 0;
+  unsigned char index[64][4];
+  memset(index, 0, sizeof index);
+  unsigned char pr = 0, pg = 0, pb = 0;
+  int run = 0;
+  for (size_t i = 0; i < n; i++) {
+    unsigned char r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+    if (r == pr && g == pg && b == pb) {
+      if (++run == 62 || i + 1 == n) { *q++ = 0xC0 | (run - 1); run = 0; }
+      continue;
+    }
+    if (run) { *q++ = 0xC0 | (run - 1); run = 0; }
+    int hpos = (r * 3 + g * 5 + b * 7 + 255 * 11) % 64;
+    if (index[hpos][0] == r && index[hpos][1] == g && index[hpos][2] == b && index[hpos][3] == 255) {
+      *q++ = (unsigned char)hpos;
+    } else {
+      index[hpos][0] = r; index[hpos][1] = g; index[hpos][2] = b; index[hpos][3] = 255;
+      signed char dr = (signed char)(r - pr), dg = (signed char)(g - pg), db = (signed char)(b - pb);
+      signed char dr_dg = (signed char)(dr - dg), db_dg = (signed char)(db - dg);
+      if (dr > -3 && dr < 2 && dg > -3 && dg < 2 && db > -3 && db < 2) {
+        *q++ = 0x40 | ((dr + 2) << 4) | ((dg + 2) << 2) | (db + 2);
+      } else if (dr_dg > -9 && dr_dg < 8 && dg > -33 && dg < 32 && db_dg > -9 && db_dg < 8) {
+        *q++ = 0x80 | (dg + 32);
+        *q++ = ((dr_dg + 8) << 4) | (db_dg + 8);
+      } else {
+        *q++ = 0xFE; *q++ = r; *q++ = g; *q++ = b;
+      }
+    }
+    pr = r; pg = g; pb = b;
+  }
+  static unsigned char const end[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+  memcpy(q, end, 8); q += 8;
+  int ok = fwrite(hd, 1, 14, o) == 14 && fwrite(buf, 1, (size_t)(q - buf), o) == (size_t)(q - buf);
+  free(buf);
+  return ok;
+}
+static int write_image(char const *path, unsigned char const *rgb, int w, int h) {
+  FILE *o = fopen(path, "wb");
+  if (!o) return 0;
+  size_t len = strlen(path);
+  int ok;
+  if (len > 4 && !strcmp(path + len - 4, ".png")) ok = write_png(o, rgb, w, h);
+  else if (len > 4 && !strcmp(path + len - 4, ".qoi")) ok = write_qoi(o, rgb, w, h);
+  else ok = fprintf(o, "P6\n%d %d\n255\n", w, h) > 0 && fwrite(rgb, 1, (size_t)w * h * 3, o) == (size_t)w * h * 3;   /* .ppm */
+  return fclose(o) == 0 && ok;
+}
 
 /* driver.c:685-728 + :758-775: model file -> triangles, materials, images, camera; environment map; scene_init */
 static int main_model(int argc, char **argv, int width, int height, int samples, int bounces, int n_threads) {
@@ -184,11 +284,7 @@ static int render_and_write(Scene *scene_p, int width, int height, int samples, 
     image = denoised;
   }
 
-  FILE *o = fopen(out_path, "wb");
-  if (!o) return die("cannot open output");
-  fprintf(o, "P6\n%d %d\n255\n", width, height);
-  fwrite(image.pixels.data, 1, (size_t)image.pixels.len, o);
-  fclose(o);
+  if (!write_image(out_path, image.pixels.data, width, height)) return die("cannot write output");
   printf("driver_min: %dx%d, %d spp, %d bounces, %d thread(s), chunk counter %d -> %s\n", width, height, samples, bounces,
          n_threads, (int)ctx._current_chunk, out_path);
   return 0;
