@@ -262,6 +262,14 @@ static int ensure_device(Device &D) {            // D.mutex held (or single-thre
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, D.phys));
   D.num_cus = prop.multiProcessorCount;
+  if (D.slot != 0 && D.phys != g_primary) {
+    // this device sends its tiles into device 0's buffer: direct xGMI copies when peer access can be enabled, staged ones otherwise
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, D.phys, g_primary) == hipSuccess && can) {
+      hipError_t pe = hipDeviceEnablePeerAccess(g_primary, 0);
+      if (pe != hipSuccess) (void)hipGetLastError();      // (already enabled, or refused: hipMemcpyPeerAsync still works)
+    }
+  }
   D.ready = true;
   return 0;
 }

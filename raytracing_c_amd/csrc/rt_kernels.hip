@@ -1005,12 +1005,15 @@ extern "C" int rt_launch_test_trace_stream(const RT_KParams *P, int n, const flo
 
 template <int WAVES, bool LDSN, int MINW, bool SHORT_DIV>
 static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set && smem_bytes > 48 * 1024) {
+  // (the attribute belongs to the kernel ON ONE DEVICE: a frame spread over N GPUs launches from N devices)
+  static unsigned attr_devices = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (smem_bytes > 48 * 1024 && (dev >= 32 || !(__atomic_load_n(&attr_devices, __ATOMIC_RELAXED) & (1u << dev)))) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    if (dev < 32) __atomic_fetch_or(&attr_devices, 1u << dev, __ATOMIC_RELAXED);
   }
   hipLaunchKernelGGL((rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>), dim3((n_waves + WAVES - 1) / WAVES),
                      dim3(WAVES * 64), smem_bytes, stream, *P);

@@ -483,12 +483,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 // n_waves = total wavefronts wanted; smem_bytes = dynamic LDS per workgroup (variants >= 2).
 template <int WAVES, bool LDSN, bool STATS, int MINW>
 static int launch_sched(const RT_KParams *P, int n_waves, int smem_bytes, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set && smem_bytes > 48 * 1024) {
+  if (smem_bytes > 48 * 1024) {          // (per device; the diagnostic generations set it at every launch)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_sched<WAVES, LDSN, STATS, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((rt_path_kernel_sched<WAVES, LDSN, STATS, MINW>), dim3((n_waves + WAVES - 1) / WAVES), dim3(WAVES * 64),
                      smem_bytes, stream, *P);
