@@ -719,10 +719,9 @@ __device__ __forceinline__ int cost_bucket(uint32_t c) {
 __global__ __launch_bounds__(1024) void rt_prepare_kernel(int n_tiles, uint32_t *tile_next, uint32_t *open_groups,
                                                           unsigned long long *counters, uint32_t *work_head, uint32_t *cost_cur,
                                                           const uint32_t *cost_prev, uint32_t *order) {
-  // counting sort without a single contended atomic: every wave counts its own share of the tiles per bucket (lanes of one
-  // batch that fall into the same bucket are found with a ballot and counted by one lane), one scan turns the 16 x 132
-  // counts into per-(wave, bucket) start positions, and every wave scatters its tiles from its own cursors.  (Most tiles of
-  // a frame fall into a handful of buckets: LDS atomics on those few words took 100-170 us for the 32 400 tiles of 1080p.)
+  // counting sort: every wave counts its own share of the tiles per bucket in its own LDS row, one scan turns the 16 x 132
+  // counts into per-(wave, bucket) start positions, and every wave scatters its tiles from its own cursors.  (One shared
+  // row of LDS atomics took 100-170 us for the 32 400 tiles of 1080p: most tiles fall into a handful of buckets.)
   __shared__ uint32_t hist[16][RT_ORDER_BUCKETS];
   __shared__ uint32_t bucket_start[RT_ORDER_BUCKETS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -740,19 +739,34 @@ __global__ __launch_bounds__(1024) void rt_prepare_kernel(int n_tiles, uint32_t 
     }
   }
   if (!cost_prev || !order) return;
+  // a wave owns the tiles [wave * per_wave, (wave + 1) * per_wave) and its own row of counters in LDS.  Per batch of 64
+  // tiles the (up to) three most common buckets are counted by ballot -- neighbouring tiles cost about the same, most of a
+  // batch falls into one or two buckets, and 64 LDS atomics on one word serialise -- the stragglers by LDS atomics.
   for (int b = lane; b < RT_ORDER_BUCKETS; b += 64) hist[wave][b] = 0u;
-  // a wave owns the tiles [wave * per_wave, (wave + 1) * per_wave): contiguous, so that order inside a bucket is by tile
   const int per_wave = ((n_tiles + 15) / 16 + 63) & ~63;
   const int first = wave * per_wave, last = first + per_wave < n_tiles ? first + per_wave : n_tiles;
-  for (int base = first; base < last; base += 64) {
-    const int i = base + lane;
-    const int bkt = i < last ? cost_bucket(cost_prev[i]) : -1;
-    unsigned long long todo = __ballot(bkt >= 0);
-    while (todo) {
-      const int b0 = __builtin_amdgcn_readlane(bkt, (int)__builtin_ctzll(todo));
-      const unsigned long long m = __ballot(bkt == b0);
-      if (lane == 0) hist[wave][b0] += (uint32_t)__popcll(m);
-      todo &= ~m;
+  // (16 batches' costs are loaded together: one dependent load per batch would cost its full latency -- the cost buffer was
+  // written by the previous launch's atomics and sits at the memory side -- 32 times per wave and phase)
+  for (int group = first; group < last; group += 64 * 16) {
+    int bk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = group + 64 * k + lane;
+      bk[k] = i < last ? (int)cost_prev[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int bkt = bk[k] >= 0 ? cost_bucket((uint32_t)bk[k]) : -1;
+      unsigned long long todo = __ballot(bkt >= 0);
+#pragma unroll
+      for (int round = 0; round < 3; round++) {
+        if (!todo) break;
+        const int b0 = __builtin_amdgcn_readlane(bkt, (int)__builtin_ctzll(todo));
+        const unsigned long long m = __ballot(bkt == b0);
+        if (lane == 0) atomicAdd(&hist[wave][b0], (uint32_t)__popcll(m));
+        todo &= ~m;
+      }
+      if ((todo >> lane) & 1ull) atomicAdd(&hist[wave][bkt], 1u);
     }
   }
   __syncthreads();
@@ -767,19 +781,32 @@ __global__ __launch_bounds__(1024) void rt_prepare_kernel(int n_tiles, uint32_t 
     for (int b = RT_ORDER_BUCKETS - 1; b >= 0; b--) { uint32_t c = bucket_start[b]; bucket_start[b] = run; run += c; }
   }
   __syncthreads();
-  for (int base = first; base < last; base += 64) {
-    const int i = base + lane;
-    const int bkt = i < last ? cost_bucket(cost_prev[i]) : -1;
-    unsigned long long todo = __ballot(bkt >= 0);
-    while (todo) {
-      const int b0 = __builtin_amdgcn_readlane(bkt, (int)__builtin_ctzll(todo));
-      const unsigned long long m = __ballot(bkt == b0);
-      const uint32_t pos = bucket_start[b0] + hist[wave][b0];           // (same value for every lane: a broadcast read)
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (bkt == b0) order[pos + (uint32_t)rank] = (uint32_t)i;
-      // the wave's reads of its cursor above have returned before lane 0 moves it (one wave: LDS operations complete in order)
-      if (lane == 0) hist[wave][b0] += (uint32_t)__popcll(m);
-      todo &= ~m;
+  for (int b = lane; b < RT_ORDER_BUCKETS; b += 64) hist[wave][b] += bucket_start[b];     // this wave's cursors
+  for (int group = first; group < last; group += 64 * 16) {
+    int bk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = group + 64 * k + lane;
+      bk[k] = i < last ? (int)cost_prev[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = group + 64 * k + lane;
+      const int bkt = bk[k] >= 0 ? cost_bucket((uint32_t)bk[k]) : -1;
+      unsigned long long todo = __ballot(bkt >= 0);
+#pragma unroll
+      for (int round = 0; round < 3; round++) {
+        if (!todo) break;
+        const int b0 = __builtin_amdgcn_readlane(bkt, (int)__builtin_ctzll(todo));
+        const unsigned long long m = __ballot(bkt == b0);
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&hist[wave][b0], (uint32_t)__popcll(m));
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (bkt == b0) order[pos + (uint32_t)rank] = (uint32_t)i;
+        todo &= ~m;
+      }
+      if ((todo >> lane) & 1ull) order[atomicAdd(&hist[wave][bkt], 1u)] = (uint32_t)i;
     }
   }
 }
