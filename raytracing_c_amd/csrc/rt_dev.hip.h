@@ -18,6 +18,12 @@
 #include "rt_device.h"
 #include "../../include/rt_math.h"
 
+#ifndef RT_SCALAR_TEX
+#define RT_SCALAR_TEX 1
+#endif
+#ifndef RT_SCALAR_MATS
+#define RT_SCALAR_MATS 1
+#endif
 #ifndef RT_LEAF_PAIRS
 #define RT_LEAF_PAIRS 0      // 1: leaf tiles fetched by lane pairs (leaf_test_pair) -- bit-exact, measured slower (profiles/r03_experiments.md)
 #endif
@@ -506,7 +512,22 @@ __device__ __forceinline__ rt_v3 texel_rgb(uint32_t t) {
 
 template <class PT>
 __device__ __forceinline__ rt_v3 tex_bilinear(const PT &P, int tex, float tx, float ty) {
-  RT_DTexture T = P.textures[tex];
+  RT_DTexture T;
+#if RT_SCALAR_TEX
+  {
+    // the descriptor of a texture every lane of the block samples comes through the scalar cache (see shade())
+    const int t0 = __builtin_amdgcn_readfirstlane(tex);
+    if (__ballot(tex != t0) == 0ull) {
+      typedef const RT_DTexture __attribute__((address_space(4))) CT;
+      CT *tp = (CT *)(unsigned long long)(P.textures + t0);
+      T.offset = tp->offset; T.width = tp->width; T.height = tp->height; T.stride = tp->stride;
+    } else {
+      T = P.textures[tex];
+    }
+  }
+#else
+  T = P.textures[tex];
+#endif
   if (tx < 0) tx += (float)(-(int)tx + 1);
   if (ty < 0) ty += (float)(-(int)ty + 1);
   tx = rt_fractf(tx);
@@ -695,8 +716,25 @@ template <class PT>
 __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, uint32_t &rng,
                                       rt_v3 &out_dir, rt_v3 &tint, rt_v3 &emission, bool &terminate,
                                       LaneCounters &cn) {
-  const float *mb = P.mats + (size_t)mat * 20;
-  float4 m0 = ld4(mb, 0), m1 = ld4(mb, 1), m2 = ld4(mb, 2), m3 = ld4(mb, 3), m4 = ld4(mb, 4);
+  float4 m0, m1, m2, m3, m4;
+#if RT_SCALAR_MATS
+  // one material for every lane of this block (the helmet has one material, most blocks of any scene have one): the 80-byte
+  // record comes through the scalar cache -- one round trip of ~100 cycles instead of a vector load's several hundred --
+  // and the texture indices it holds are wave-uniform
+  const int mat0 = __builtin_amdgcn_readfirstlane(mat);
+  if (__ballot(mat != mat0) == 0ull) {
+    cfloat *sb = as_scalar_ptr(P.mats) + (size_t)mat0 * 20;
+    m0 = make_float4(sb[0], sb[1], sb[2], sb[3]);
+    m1 = make_float4(sb[4], sb[5], sb[6], sb[7]);
+    m2 = make_float4(sb[8], sb[9], sb[10], sb[11]);
+    m3 = make_float4(sb[12], sb[13], sb[14], sb[15]);
+    m4 = make_float4(sb[16], sb[17], sb[18], sb[19]);
+  } else
+#endif
+  {
+    const float *mb = P.mats + (size_t)mat * 20;
+    m0 = ld4(mb, 0); m1 = ld4(mb, 1); m2 = ld4(mb, 2); m3 = ld4(mb, 3); m4 = ld4(mb, 4);
+  }
   int tex_albedo = as_i(m3.x), tex_normal = as_i(m3.y), tex_mr = as_i(m3.z), tex_em = as_i(m3.w);
   int kind = as_i(m4.x);
 
