@@ -352,6 +352,30 @@ def bvh_compare(rt, abi, args, cfg, image_ref, steps=3):
         rt.lib.rt_scene_release(d)
 
 
+def boundary_cost(rt, abi, hs, frames=8):
+    """Side measurement for config.boundary: frames through the reference's own entry point render_thread_proc (the protocol of
+    driver.c:793-818: Rendering_Context, a worker thread, polling) at the reference driver's DEFAULT frame -- 1024 x 1024, 16 spp,
+    8 bounces (driver.c:733-742) -- on this scene, split into host and GPU phases by rt_get_frame_timing().  Medians over the
+    frames after the first two (upload, no schedule feedback yet).  The same through a C host: profiles/r03_boundary.md."""
+    w, h, s, b = 1024, 1024, 16, 8
+    rows = []
+    for _ in range(frames + 2):
+        r = rt.render_context(hs, w, h, s, b, n_threads=1)
+        if not r["finished"]:
+            return {"error": rt.last_error()}
+        t = abi.RT_Frame_Timing()
+        if rt.lib.rt_get_frame_timing(C.byref(t)) != 0:
+            return {"error": rt.last_error()}
+        rows.append([getattr(t, f[0]) for f in t._fields_])
+    rows = rows[2:]
+    med = [sorted(col)[len(col) // 2] for col in zip(*rows)]
+    names = [f[0] for f in abi.RT_Frame_Timing._fields_]
+    out = {"frame": f"{w}x{h}, {s} spp, {b} bounces (driver.c:733-742), via render_thread_proc", "frames": frames}
+    out.update({n: v for n, v in zip(names, med)})
+    out["non_kernel_share"] = (out["total_ms"] - out["gpu_path_ms"]) / out["total_ms"] if out["total_ms"] > 0 else None
+    return out
+
+
 def dry_run(args, world, rank):
     """CPU-only rehearsal of the N-rank plumbing: rendezvous, partition tables, tile exchange, MAX-over-ranks
     timing, one line from rank 0.  No kernel runs and the line says so."""
@@ -631,6 +655,8 @@ def main():
         }
         if world == 1 and not args.no_bvh_compare:
             out["config"]["bvh"]["sah"] = bvh_compare(rt, abi, args, cfg, host_images[(frame_no[0] - 1) & 1].numpy())
+        if world == 1 and not args.no_bvh_compare:
+            out["config"]["boundary"] = boundary_cost(rt, abi, hs)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)
         if args.save:
