@@ -1051,14 +1051,17 @@ static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipSt
 extern "C" int rt_launch_path_kernel_diag(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream);
 #endif
 
+#ifndef RT_STREAM_MINW
+#define RT_STREAM_MINW 1     // (experiment builds: 5 caps the kernel at 96 VGPRs, 6 at 80 -- profiles/r03_experiments.md)
+#endif
 // variant 5 = the tile-stream kernel, the only path kernel of the product library; 1-4 exist in the diagnostic build only
 extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
 #ifdef RT_DIAG_VARIANTS
   if (variant >= 1 && variant <= 4) return rt_launch_path_kernel_diag(P, n_waves, variant, smem_bytes, stream);
 #endif
   (void)variant;
-  return P->short_div ? launch_stream<16, true, 1, true>(P, n_waves, smem_bytes, stream)
-                      : launch_stream<16, true, 1, false>(P, n_waves, smem_bytes, stream);
+  return P->short_div ? launch_stream<16, true, RT_STREAM_MINW, true>(P, n_waves, smem_bytes, stream)
+                      : launch_stream<16, true, RT_STREAM_MINW, false>(P, n_waves, smem_bytes, stream);
 }
 
 extern "C" int rt_launch_resolve(int width, int height, int samples, int chunks_x, const int32_t *local_chunks,
