@@ -444,8 +444,13 @@ def main():
     torch.cuda.set_device(local_rank)
     if rt.lib.rt_init(local_rank) != 0:
         raise RuntimeError("rt_init: " + rt.last_error())
+    wavefront = False
     if args.pipeline == "wavefront":
+        # measurement only: the wavefront pipeline exists in the diagnostic library, not in the product (include/rt_hip_diag.h)
+        if not rt.native.LIB_PATH.endswith("librt_hip_diag.so"):
+            raise SystemExit("--pipeline wavefront needs RT_LIB_PATH=raytracing_c_amd/librt_hip_diag.so (make -C raytracing_c_amd/csrc diag)")
         rt.lib.rt_set_pipeline(1)
+        wavefront = True
     dist = None
     force_dist = world == 1 and os.environ.get("RT_BENCH_FORCE_DIST") == "1"     # rehearsal: RCCL path with one rank
     if force_dist:
@@ -622,9 +627,9 @@ def main():
         if args.config in names and tuple(CONFIGS[args.config][1:5]) == (w, h, s, b):
             workload += f" (BASELINE.json configs[{names.index(args.config)}])"
         prof = measured_profile(workload)
-        pipeline = "wavefront pipeline (rt_wf_camera / shade / trace kernels)" if rt.lib.rt_get_pipeline() == 1 else \
+        pipeline = "wavefront pipeline (rt_wf_camera / shade / trace kernels; diagnostic library)" if wavefront else \
             "rt_path_kernel_stream<16, true, 1, short reciprocal> (the product's one path kernel)"
-        if prof is not None and rt.lib.rt_get_pipeline() == 1:
+        if prof is not None and wavefront:
             prof = None                                 # the committed profiles are of the tile-stream kernel
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,

@@ -8,16 +8,33 @@
  * 239-240, raytracer.c:526) and ships no tests, so their ulp-level behaviour is
  * unpinned.  This header defines it ONCE, using only
  * operations that IEEE-754 rounds identically on x86-64 and gfx950:
- *   + - * /  sqrt  floor  int<->float conversion  comparisons  bit casts.
- * plus EXPLICIT fused multiply-adds (rt_fmaf = fmaf, one rounding, identical on
- * x86-64 FMA units and gfx950 v_fma_f32) inside the polynomial kernels of the
- * elementary functions only -- they replace libm calls, so there is no reference
- * operation order to preserve there, and Horner steps cost one instruction
- * instead of two.  Both compilers MUST be run with -ffp-contract=off (no
- * IMPLICIT contraction anywhere) and without fast-math (hipcc additionally
- * keeps its default correctly rounded fp32 divide/sqrt); then every function
- * below returns bit-identical results on CPU and GPU, which is what lets tests/
- * demand bit-exact images instead of a tolerance.
+ *   + - * /  sqrt  floor  int<->float conversion  comparisons  bit casts
+ * plus EXPLICIT fused multiply-adds (fmaf: one rounding, identical on x86-64 FMA
+ * units and gfx950 v_fma_f32).  Both compilers MUST be run with
+ * -ffp-contract=off (no IMPLICIT contraction anywhere) and without fast-math
+ * (hipcc additionally keeps its default correctly rounded fp32 divide/sqrt);
+ * then every function below returns bit-identical results on CPU and GPU, which
+ * is what lets tests/ demand bit-exact images instead of a tolerance.
+ *
+ * Numeric contract v2 (round 4), "explicit FMA":
+ *   * the polynomial kernels of the elementary functions use rt_fmaf Horner
+ *     steps (they replace libm calls: there is no reference operation order);
+ *   * every  a*b + c  of the path's vector algebra -- dots, crosses, lerps,
+ *     reflections, the 3x3 products, point = origin + t * direction -- is ONE
+ *     rt_madd(a, b, c): the multiply-add a CPU build of the reference gets from
+ *     GNU C's default -ffp-contract=fast (raytracer.c:131-147 are
+ *     `a*b + c*d + e*f` on vector types) and a single v_fma_f32 on gfx950.
+ *     Sums of products are folded LEFT TO RIGHT:
+ *         a0*b0 + a1*b1 + a2*b2  ==  madd(a2, b2, madd(a1, b1, a0*b0)),
+ *     differences  a*b - c*d  as  madd(a, b, -(c*d)).
+ *   * -DRT_MATH_NO_FMA (on BOTH compilers) restores contract v1: rt_madd(a,b,c)
+ *     is a*b + c with two roundings, nothing else changes.  The two contracts are
+ *     the same estimator (tests/test_oracle_contracts.py); bit parity between CPU
+ *     and GPU holds under either.
+ *   * functions with the suffix _plain never fuse: the BVH / tangent-frame
+ *     builders (scene.c arithmetic, pinned by the survey's shape table and
+ *     traversal statistics) and the denoiser (pinned by a numpy restatement)
+ *     keep their arithmetic under both contracts.
  *
  * Polynomial coefficients are the classic single-precision minimax sets
  * (Cephes, S. Moshier) for log/exp/sin/cos/atan/asin.
@@ -57,6 +74,24 @@ RT_FN float rt_floorf(float x) { return __builtin_floorf(x); }
 RT_FN float rt_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   /* a*b+c, ONE rounding */
 RT_FN float rt_fractf(float x) { return x - rt_floorf(x); }   /* raytracer.c:582 */
 
+/* The multiply-add of the numeric contract (header comment): fused under contract v2, two roundings under
+ * -DRT_MATH_NO_FMA (contract v1). */
+#ifdef RT_MATH_NO_FMA
+#define RT_MATH_CONTRACT 1
+RT_FN float rt_madd(float a, float b, float c) { return a * b + c; }
+#else
+#define RT_MATH_CONTRACT 2
+RT_FN float rt_madd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+/* a0*b0 + a1*b1 + a2*b2, folded left to right */
+RT_FN float rt_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return rt_madd(a2, b2, rt_madd(a1, b1, a0 * b0));
+}
+/* a0*b0 + a1*b1 */
+RT_FN float rt_dot2(float a0, float b0, float a1, float b1) { return rt_madd(a1, b1, a0 * b0); }
+/* a*b - c*d */
+RT_FN float rt_diff2(float a, float b, float c, float d) { return rt_madd(a, b, -(c * d)); }
+
 /* ---- RNG (common.h:13-24) --------------------------------------------------- */
 
 /* One step of the reference generator: returns the new state. */
@@ -91,11 +126,19 @@ RT_FN rt_v3 rt_v3_add(rt_v3 a, rt_v3 b) { return rt_v3_make(a.x + b.x, a.y + b.y
 RT_FN rt_v3 rt_v3_sub(rt_v3 a, rt_v3 b) { return rt_v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_FN rt_v3 rt_v3_mul(rt_v3 a, rt_v3 b) { return rt_v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_FN rt_v3 rt_v3_scale(rt_v3 a, float s) { return rt_v3_make(a.x * s, a.y * s, a.z * s); }
-RT_FN float rt_v3_dot(rt_v3 a, rt_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_FN float rt_v3_dot(rt_v3 a, rt_v3 b) { return rt_dot3(a.x, b.x, a.y, b.y, a.z, b.z); }
+/* v * s + w */
+RT_FN rt_v3 rt_v3_madd(rt_v3 v, float s, rt_v3 w) { return rt_v3_make(rt_madd(v.x, s, w.x), rt_madd(v.y, s, w.y), rt_madd(v.z, s, w.z)); }
+/* a * b + c, component-wise */
+RT_FN rt_v3 rt_v3_mul_add(rt_v3 a, rt_v3 b, rt_v3 c) { return rt_v3_make(rt_madd(a.x, b.x, c.x), rt_madd(a.y, b.y, c.y), rt_madd(a.z, b.z, c.z)); }
+/* a * s + b * t + c * u (tangent_to_world, driver.c:398; barycentric interpolation, raytracer.c:167-176) */
+RT_FN rt_v3 rt_v3_comb3(rt_v3 a, float s, rt_v3 b, float t, rt_v3 c, float u) {
+  return rt_v3_make(rt_dot3(a.x, s, b.x, t, c.x, u), rt_dot3(a.y, s, b.y, t, c.y, u), rt_dot3(a.z, s, b.z, t, c.z, u));
+}
 
 /* common.h:54-60 */
 RT_FN rt_v3 rt_v3_cross(rt_v3 a, rt_v3 b) {
-  return rt_v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+  return rt_v3_make(rt_diff2(a.y, b.z, a.z, b.y), rt_diff2(a.z, b.x, a.x, b.z), rt_diff2(a.x, b.y, a.y, b.x));
 }
 
 /* codin vec3_normalize: defined here as v * (1 / sqrt(v.v)). */
@@ -105,7 +148,7 @@ RT_FN rt_v3 rt_v3_normalize(rt_v3 v) {
 }
 
 /* lerp_f32 of driver.c:283-285; codin vec3_lerp is defined component-wise the same. */
-RT_FN float rt_lerpf(float x, float y, float t) { return x * (1.0f - t) + y * t; }
+RT_FN float rt_lerpf(float x, float y, float t) { return rt_madd(y, t, x * (1.0f - t)); }
 RT_FN rt_v3 rt_v3_lerp(rt_v3 a, rt_v3 b, float t) {
   return rt_v3_make(rt_lerpf(a.x, b.x, t), rt_lerpf(a.y, b.y, t), rt_lerpf(a.z, b.z, t));
 }
@@ -113,8 +156,37 @@ RT_FN rt_v3 rt_v3_lerp(rt_v3 a, rt_v3 b, float t) {
 /* codin vec3_reflect(v, n) = v - 2 (v.n) n (convention checked against
  * output.png by the survey probe). */
 RT_FN rt_v3 rt_v3_reflect(rt_v3 v, rt_v3 n) {
-  return rt_v3_sub(v, rt_v3_scale(n, 2.0f * rt_v3_dot(v, n)));
+  return rt_v3_madd(n, -(2.0f * rt_v3_dot(v, n)), v);
 }
+
+/* ---- never-fused forms (builders, denoiser: see the header comment) ------------ */
+RT_FN float rt_v3_dot_plain(rt_v3 a, rt_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_FN rt_v3 rt_v3_cross_plain(rt_v3 a, rt_v3 b) {
+  return rt_v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_FN rt_v3 rt_v3_normalize_plain(rt_v3 v) {
+  float inv = 1.0f / rt_sqrtf(rt_v3_dot_plain(v, v));
+  return rt_v3_scale(v, inv);
+}
+RT_FN float rt_lerpf_plain(float x, float y, float t) { return x * (1.0f - t) + y * t; }
+
+/* ---- slab arithmetic (ray_aabbs_hit_8, raytracer.c:198-210) ---------------------
+ * Contract v1 and every ray that is not NaN-free:  t = (plane - o) * inv.
+ * Contract v2, NaN-free rays:  t = fma(plane, inv, bias) with bias = -(o * inv), ONE instruction per plane instead
+ * of two.  A ray is NaN-free ("fast") when, per axis, the reciprocal direction and the bias are finite: then the
+ * exact product plane * inv is a finite real, bias is finite, and the fused result is finite or an overflowed
+ * infinity -- never NaN -- and it is monotonic in `plane`, which the device code's pick-by-address relies on. */
+RT_FN float rt_slab_bias(float o, float inv) { return -(o * inv); }
+RT_FN int rt_slab_fast(float inv_x, float inv_y, float inv_z, float bias_x, float bias_y, float bias_z) {
+  return (rt_absf(inv_x) < RT_INF) && (rt_absf(inv_y) < RT_INF) && (rt_absf(inv_z) < RT_INF) &&
+         (rt_absf(bias_x) < RT_INF) && (rt_absf(bias_y) < RT_INF) && (rt_absf(bias_z) < RT_INF);
+}
+RT_FN float rt_slab_t_exact(float plane, float o, float inv) { return (plane - o) * inv; }
+#ifdef RT_MATH_NO_FMA
+RT_FN float rt_slab_t_fast(float plane, float o, float inv, float bias) { (void)bias; return (plane - o) * inv; }
+#else
+RT_FN float rt_slab_t_fast(float plane, float o, float inv, float bias) { (void)o; return __builtin_fmaf(plane, inv, bias); }
+#endif
 
 /* ---- elementary functions ---------------------------------------------------- */
 
@@ -240,7 +312,7 @@ RT_FN rt_v3 rt_srgb_to_linear(rt_v3 c) {
 }
 
 RT_FN float rt_linear_to_srgb(float c) {
-  return (c <= 0.0031308f) ? (12.92f * c) : (1.055f * rt_powf(c, 1.0f / 2.4f) - 0.055f);
+  return (c <= 0.0031308f) ? (12.92f * c) : rt_madd(1.055f, rt_powf(c, 1.0f / 2.4f), -0.055f);
 }
 
 /* ---- primary-ray jitter (raytracer.c:584-594) ---------------------------------- */
@@ -249,6 +321,8 @@ RT_FN float rt_hash12(float px, float py) {
   float p3x = rt_fractf(px * 0.1031f);
   float p3y = rt_fractf(py * 0.1031f);
   float p3z = rt_fractf(px * 0.1031f);
+  /* NOT fused under either contract: a hash amplifies every rounding, and the reference's AVX2 intrinsics
+   * (_mm256_mul_ps / _mm256_add_ps, raytracer.c:584-594) are what tests/test_oracle_kat.py restates; once per path */
   float d = p3x * (p3y + 33.33f) + p3y * (p3z + 33.33f) + p3z * (p3x + 33.33f);
   return rt_fractf((p3x + p3y + d * 2.0f) * (p3z + d));
 }

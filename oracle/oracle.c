@@ -93,12 +93,12 @@ static bool ray_triangles_hit_8(Ray const *ray, Triangles const *triangles, isiz
     tl_bary_u = t1;
     tl_bary_v = t2;
 
-    hit->point = U(rt_v3_add(org, rt_v3_scale(dir, min)));
-    hit->normal.x = aos->normal_a.x * t0 + aos->normal_b.x * t1 + aos->normal_c.x * t2;
-    hit->normal.y = aos->normal_a.y * t0 + aos->normal_b.y * t1 + aos->normal_c.y * t2;
-    hit->normal.z = aos->normal_a.z * t0 + aos->normal_b.z * t1 + aos->normal_c.z * t2;
-    hit->tex_coords.x = aos->tex_coords_a.x * t0 + aos->tex_coords_b.x * t1 + aos->tex_coords_c.x * t2;
-    hit->tex_coords.y = aos->tex_coords_a.y * t0 + aos->tex_coords_b.y * t1 + aos->tex_coords_c.y * t2;
+    hit->point = U(rt_v3_madd(dir, min, org));
+    hit->normal.x = rt_dot3(aos->normal_a.x, t0, aos->normal_b.x, t1, aos->normal_c.x, t2);
+    hit->normal.y = rt_dot3(aos->normal_a.y, t0, aos->normal_b.y, t1, aos->normal_c.y, t2);
+    hit->normal.z = rt_dot3(aos->normal_a.z, t0, aos->normal_b.z, t1, aos->normal_c.z, t2);
+    hit->tex_coords.x = rt_dot3(aos->tex_coords_a.x, t0, aos->tex_coords_b.x, t1, aos->tex_coords_c.x, t2);
+    hit->tex_coords.y = rt_dot3(aos->tex_coords_a.y, t0, aos->tex_coords_b.y, t1, aos->tex_coords_c.y, t2);
     hit->shader     = aos->shader;
     hit->normal_geo = aos->normal;
     hit->tangent    = aos->tangent;
@@ -115,14 +115,28 @@ static void ray_aabbs_hit_8(Ray const *ray, f32 t_min, f32 t_max, BVH_Node const
   f32 inv_y = 1.0f / ray->direction.y;
   f32 inv_z = 1.0f / ray->direction.z;
   f32 ox = ray->position.x, oy = ray->position.y, oz = ray->position.z;
+  /* numeric contract v2 (rt_math.h): NaN-free rays take every plane distance from ONE fused multiply-add,
+   * fma(plane, inv, -(o * inv)); the others keep the reference's (plane - o) * inv (deviation D9) */
+  f32 bias_x = rt_slab_bias(ox, inv_x), bias_y = rt_slab_bias(oy, inv_y), bias_z = rt_slab_bias(oz, inv_z);
+  bool fast = rt_slab_fast(inv_x, inv_y, inv_z, bias_x, bias_y, bias_z);
 
   for (int k = 0; k < 8; k++) {
-    f32 t0x = (node->min_x[k] - ox) * inv_x;
-    f32 t0y = (node->min_y[k] - oy) * inv_y;
-    f32 t0z = (node->min_z[k] - oz) * inv_z;
-    f32 t1x = (node->max_x[k] - ox) * inv_x;
-    f32 t1y = (node->max_y[k] - oy) * inv_y;
-    f32 t1z = (node->max_z[k] - oz) * inv_z;
+    f32 t0x, t0y, t0z, t1x, t1y, t1z;
+    if (fast) {
+      t0x = rt_slab_t_fast(node->min_x[k], ox, inv_x, bias_x);
+      t0y = rt_slab_t_fast(node->min_y[k], oy, inv_y, bias_y);
+      t0z = rt_slab_t_fast(node->min_z[k], oz, inv_z, bias_z);
+      t1x = rt_slab_t_fast(node->max_x[k], ox, inv_x, bias_x);
+      t1y = rt_slab_t_fast(node->max_y[k], oy, inv_y, bias_y);
+      t1z = rt_slab_t_fast(node->max_z[k], oz, inv_z, bias_z);
+    } else {
+      t0x = rt_slab_t_exact(node->min_x[k], ox, inv_x);
+      t0y = rt_slab_t_exact(node->min_y[k], oy, inv_y);
+      t0z = rt_slab_t_exact(node->min_z[k], oz, inv_z);
+      t1x = rt_slab_t_exact(node->max_x[k], ox, inv_x);
+      t1y = rt_slab_t_exact(node->max_y[k], oy, inv_y);
+      t1z = rt_slab_t_exact(node->max_z[k], oz, inv_z);
+    }
 
     f32 sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
     f32 bx = rt_max_ps(t0x, t1x), by = rt_max_ps(t0y, t1y), bz = rt_max_ps(t0z, t1z);
@@ -220,8 +234,8 @@ static rt_v3 sample_background_image(Image const *image, rt_v3 dir) {
     inv_pi     = (f32)(1.0 / PI_D);
     inv_two_pi = (f32)(1.0 / (2.0 * PI_D));
   }
-  f32 u = 0.5f + rt_atan2f(dir.z, dir.x) * inv_two_pi;
-  f32 v = 0.5f - rt_asinf(dir.y) * inv_pi;
+  f32 u = rt_madd(rt_atan2f(dir.z, dir.x), inv_two_pi, 0.5f);
+  f32 v = rt_madd(-rt_asinf(dir.y), inv_pi, 0.5f);
   return rt_srgb_to_linear(sample_texture_bilinear(image, u, v));
 }
 
@@ -234,7 +248,7 @@ static rt_v3 sample_cosine_hemisphere(void) {
   f32 s, c;
   rt_sincosf(angle, &s, &c);
   rt_v3 v = rt_v3_make(s * distance, c * distance, 0.0f);
-  v.z = rt_sqrtf(1.0f - distance * distance);
+  v.z = rt_sqrtf(rt_madd(-distance, distance, 1.0f));
   return v;
 }
 
@@ -243,14 +257,14 @@ static rt_v3 normal_map_apply(Image const *normal_map, f32 strength, Shader_Inpu
   rt_v3 normal = V(input->normal);
   if (normal_map) {
     rt_v3 v = sample_texture_bilinear(normal_map, input->tex_coords.x, input->tex_coords.y);
-    v = rt_v3_add(rt_v3_scale(v, 2.0f), rt_v3_make(-1.0f, -1.0f, -1.0f));
+    v = rt_v3_madd(v, 2.0f, rt_v3_make(-1.0f, -1.0f, -1.0f));
     v.y *= -1.0f;
     rt_v3 t = V(input->tangent), b = V(input->bitangent), n = V(input->normal);
     f32 s = strength;
     normal = rt_v3_normalize(rt_v3_make(
-      s * (v.x * t.x + v.y * b.x + v.z * n.x) + n.x * (1.0f - s),
-      s * (v.x * t.y + v.y * b.y + v.z * n.y) + n.y * (1.0f - s),
-      s * (v.x * t.z + v.y * b.z + v.z * n.z) + n.z * (1.0f - s)));
+      rt_madd(s, rt_dot3(v.x, t.x, v.y, b.x, v.z, n.x), n.x * (1.0f - s)),
+      rt_madd(s, rt_dot3(v.x, t.y, v.y, b.y, v.z, n.y), n.y * (1.0f - s)),
+      rt_madd(s, rt_dot3(v.x, t.z, v.y, b.z, v.z, n.z), n.z * (1.0f - s))));
   }
   return normal;
 }
@@ -286,15 +300,15 @@ static f32 luminance(rt_v3 x) { return rt_v3_dot(x, rt_v3_make(0.2126f, 0.7152f,
 
 static f32 pow5(f32 m) { return m * m * m * m * m; }
 
-static f32 fresnel_schlick_f32(f32 f0, f32 f90, f32 theta) { return f0 + (f90 - f0) * pow5(1.0f - theta); }
+static f32 fresnel_schlick_f32(f32 f0, f32 f90, f32 theta) { return rt_madd(f90 - f0, pow5(1.0f - theta), f0); }
 
 static rt_v3 fresnel_schlick_vec3(rt_v3 f0, f32 f90, f32 theta) {
-  return rt_v3_add(f0, rt_v3_scale(rt_v3_sub(rt_v3_make(f90, f90, f90), f0), pow5(1.0f - theta)));
+  return rt_v3_madd(rt_v3_sub(rt_v3_make(f90, f90, f90), f0), pow5(1.0f - theta), f0);
 }
 
 static f32 distribution_GGX(f32 roughness, f32 NoH) {   /* k == 2 at every call site */
   f32 a2 = roughness * roughness;
-  f32 d  = (NoH * NoH) * (a2 * a2 - 1.0f) + 1.0f;
+  f32 d  = rt_madd(NoH * NoH, rt_madd(a2, a2, -1.0f), 1.0f);
   return a2 / (RT_PI * (d * d));
 }
 
@@ -303,7 +317,7 @@ static f32 smith_G(f32 NDotV, f32 alpha2) {
   f32 b = NDotV * NDotV;
   /* driver.c:220 `(2.0 * NDotV) / (...)`: the double literal makes this a double division (D8) */
   if (tl_literal) return (f32)((2.0 * (double)NDotV) / (double)(NDotV + rt_sqrtf(a + b - a * b)));
-  return (2.0f * NDotV) / (NDotV + rt_sqrtf(a + b - a * b));
+  return (2.0f * NDotV) / (NDotV + rt_sqrtf(rt_madd(-a, b, a + b)));
 }
 
 static f32 geometry_term(f32 NoL, f32 NoV, f32 roughness) {
@@ -315,7 +329,7 @@ static f32 geometry_term(f32 NoL, f32 NoV, f32 roughness) {
 static rt_v3 sample_GGX_VNDF(rt_v3 Vv, f32 ax, f32 ay) {
   rt_v3 Vh = rt_v3_normalize(rt_v3_make(ax * Vv.x, ay * Vv.y, Vv.z));
 
-  f32 lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+  f32 lensq = rt_dot2(Vh.x, Vh.x, Vh.y, Vh.y);
   rt_v3 T1 = lensq > 0.0f ? rt_v3_scale(rt_v3_make(-Vh.y, Vh.x, 0.0f), 1.0f / rt_sqrtf(lensq)) : rt_v3_make(1, 0, 0);
   rt_v3 T2 = rt_v3_cross(Vh, T1);
 
@@ -329,18 +343,18 @@ static rt_v3 sample_GGX_VNDF(rt_v3 Vv, f32 ax, f32 ay) {
   rt_sincosf(phi, &sn, &cs);
   f32 t1 = r * cs;
   f32 t2 = r * sn;
-  f32 s  = 0.5f * (1.0f + Vh.z);           /* the double form gives the same f32: the halving is exact */
+  f32 s  = rt_madd(0.5f, Vh.z, 0.5f);      /* 0.5 * (1 + Vh.z) in one rounding; the literal (double) form rounds once too */
   f32 tail;
   if (tl_literal) {
     t2   = (f32)((1.0 - (double)s) * (double)rt_sqrtf((f32)(1.0 - (double)(t1 * t1))) + (double)(s * t2));
     double rest = 1.0 - (double)(t1 * t1) - (double)(t2 * t2);
     tail = rt_sqrtf((f32)(rest > 0.0 ? rest : 0.0));
   } else {
-    t2   = (1.0f - s) * rt_sqrtf(1.0f - t1 * t1) + s * t2;
-    tail = rt_sqrtf(rt_max_ps(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    t2   = rt_madd(1.0f - s, rt_sqrtf(rt_madd(-t1, t1, 1.0f)), s * t2);
+    tail = rt_sqrtf(rt_max_ps(0.0f, rt_madd(-t2, t2, rt_madd(-t1, t1, 1.0f))));
   }
 
-  rt_v3 Nh = rt_v3_add(rt_v3_add(rt_v3_scale(T1, t1), rt_v3_scale(T2, t2)), rt_v3_scale(Vh, tail));
+  rt_v3 Nh = rt_v3_comb3(T1, t1, T2, t2, Vh, tail);
 
   return rt_v3_normalize(rt_v3_make(ax * Nh.x, ay * Nh.y, rt_max_ps(0.0f, Nh.z)));
 }
@@ -353,7 +367,7 @@ static f32 pdf_GGX_VNDF(f32 NoH, f32 NoV, f32 roughness) {
 }
 
 static rt_v3 disney_eval_diffuse(rt_v3 base_color, f32 NoL, f32 NoV, f32 LoH, f32 roughness) {
-  f32 FD90 = 0.5f + 2.0f * roughness * LoH * LoH;
+  f32 FD90 = rt_madd(2.0f * roughness * LoH, LoH, 0.5f);
   f32 a = fresnel_schlick_f32(1.0f, FD90, NoL);
   f32 b = fresnel_schlick_f32(1.0f, FD90, NoV);
   return rt_v3_scale(base_color, (a * b / RT_PI));
@@ -482,9 +496,7 @@ static void oracle_disney_shader_proc(rawptr _data, Shader_Input const *input, S
   sample_disney_BRDF(&brdf_data, in_dir, &o, brdf);
 
   /* tangent_to_world: columns t, b, normal */
-  output->direction.x = t.x * o.x + b.x * o.y + normal.x * o.z;
-  output->direction.y = t.y * o.x + b.y * o.y + normal.y * o.z;
-  output->direction.z = t.z * o.x + b.z * o.y + normal.z * o.z;
+  output->direction = U(rt_v3_comb3(t, o.x, b, o.y, normal, o.z));
 
   if (brdf[3] > 0.0f) {
     output->tint.x = brdf[0] / brdf[3];
@@ -499,7 +511,7 @@ static void oracle_disney_shader_proc(rawptr _data, Shader_Input const *input, S
 static void oracle_debug_shader_proc(rawptr _data, Shader_Input const *input, Shader_Output *output) {
   PBR_Shader_Data const *data = (PBR_Shader_Data const *)_data;
   rt_v3 normal = normal_map_apply(data->texture_normal, data->normal_map_strength, input);
-  output->emission  = U(rt_v3_add(rt_v3_scale(normal, 0.5f), rt_v3_make(0.5f, 0.5f, 0.5f)));
+  output->emission  = U(rt_v3_madd(normal, 0.5f, rt_v3_make(0.5f, 0.5f, 0.5f)));
   output->terminate = true;
 }
 
@@ -517,7 +529,7 @@ static rt_v3 cast_ray(Scene const *scene, Oracle_Config const *cfg, Ray ray, isi
     if (hit.distance != RT_INF) {
       rt_v3 rd = V(ray.direction);
       if (rt_v3_dot(V(hit.normal_geo), rd) > 0.0f || rt_v3_dot(V(hit.normal), rd) > 0.0f) {
-        ray.position = U(rt_v3_add(V(hit.point), rt_v3_scale(rd, RT_EPS)));
+        ray.position = U(rt_v3_madd(rd, RT_EPS, V(hit.point)));
         continue;
       }
 
@@ -541,7 +553,7 @@ static rt_v3 cast_ray(Scene const *scene, Oracle_Config const *cfg, Ray ray, isi
         hit.shader.proc(hit.shader.data, &shader_input, &shader_output);
       }
 
-      emission = rt_v3_add(emission, rt_v3_mul(V(shader_output.emission), accumulated_tint));
+      emission = rt_v3_mul_add(V(shader_output.emission), accumulated_tint, emission);
       if (shader_output.terminate) break;
 
       ray.direction    = shader_output.direction;
@@ -549,7 +561,7 @@ static rt_v3 cast_ray(Scene const *scene, Oracle_Config const *cfg, Ray ray, isi
 
       f32 below = (rt_v3_dot(V(hit.normal_geo), V(shader_output.direction)) < 0.0f) ? 1.0f : 0.0f;
       f32 position_bias = (0.5f - below) * 2.0f * RT_EPS;
-      ray.position = U(rt_v3_add(V(hit.point), rt_v3_scale(V(hit.normal_geo), position_bias)));
+      ray.position = U(rt_v3_madd(V(hit.normal_geo), position_bias, V(hit.point)));
     } else {
       tl_counters.backgrounds += 1;
       rt_v3 bg;
@@ -558,7 +570,7 @@ static rt_v3 cast_ray(Scene const *scene, Oracle_Config const *cfg, Ray ray, isi
       } else {
         bg = V(scene->background.proc(scene->background.data, ray.direction));
       }
-      return rt_v3_add(rt_v3_mul(bg, accumulated_tint), emission);
+      return rt_v3_mul_add(bg, accumulated_tint, emission);
     }
   }
   return emission;
@@ -574,22 +586,22 @@ static Ray primary_ray(Camera const *camera, i32 width, i32 height, i32 x, i32 y
   f32 jitter = rt_hash12((f32)x * 50.0f + (f32)sample, (f32)y);
   f32 rand_a = jitter, rand_b = jitter;
 
-  f32 uvx = ((f32)x + rand_a - 0.5f) * 2.0f * inv_width  - 1.0f;
-  f32 uvy = ((f32)y + rand_b - 0.5f) * 2.0f * inv_height - 1.0f;
+  f32 uvx = rt_madd(((f32)x + rand_a - 0.5f) * 2.0f, inv_width,  -1.0f);
+  f32 uvy = rt_madd(((f32)y + rand_b - 0.5f) * 2.0f, inv_height, -1.0f);
 
   f32 dx = uvx * aspect;
   f32 dy = -uvy;
   f32 dz = -camera->focal_length;
 
-  f32 inv_length = 1.0f / rt_sqrtf(dx * dx + dy * dy + dz * dz);
+  f32 inv_length = 1.0f / rt_sqrtf(rt_dot3(dx, dx, dy, dy, dz, dz));
   if (tl_literal) {                        /* raytracer.c:663: the ~12-bit hardware estimate, not 1/sqrt (D2) */
     inv_length = _mm_cvtss_f32(_mm256_castps256_ps128(_mm256_rsqrt_ps(_mm256_set1_ps(dx * dx + dy * dy + dz * dz))));
   }
 
   f32 const (*m)[4] = camera->view_matrix.rows;
-  f32 rx = m[0][0] * dx + m[0][1] * dy + m[0][2] * dz;
-  f32 ry = m[1][0] * dx + m[1][1] * dy + m[1][2] * dz;
-  f32 rz = m[2][0] * dx + m[2][1] * dy + m[2][2] * dz;
+  f32 rx = rt_dot3(m[0][0], dx, m[0][1], dy, m[0][2], dz);
+  f32 ry = rt_dot3(m[1][0], dx, m[1][1], dy, m[1][2], dz);
+  f32 rz = rt_dot3(m[2][0], dx, m[2][1], dy, m[2][2], dz);
 
   Ray r;
   /* camera_position = view_matrix * (0,0,0,1), raytracer.c:612 */
@@ -899,7 +911,7 @@ void oracle_denoise_image(Image const *src, Image const *dst) {
       diff = rt_clampf(diff, 0.0f, DENOISING_THRESHOLD) / DENOISING_THRESHOLD;
       isize nc = dst->components < 3 ? dst->components : 3;
       for (isize c = 0; c < nc; c++) {                    /* store_pixel, denoiser.c:32-41 */
-        f32 v = rt_lerpf(original[c], median[c], diff);
+        f32 v = rt_lerpf_plain(original[c], median[c], diff);
         dst->pixels.data[(x + y * dst->stride) * dst->components + c] = (u8)(v * 255.999f);
       }
     }

@@ -4,7 +4,7 @@ Python here is plumbing only (ctypes mirror of include/*.h, asset loading, the
 multi-GPU launcher); every pixel is computed by librt_hip.so on gfx950.
 """
 from . import ctypes_abi as abi          # noqa: F401
-from .native import lib, NativeLibraryMissing, last_error   # noqa: F401
+from .native import lib, diag, NativeLibraryMissing, last_error   # noqa: F401
 from .scene import HostScene, build_scene, Material   # noqa: F401
 from .background import procedural_background   # noqa: F401
 from .loaders import load_model, default_camera, camera_from_trs   # noqa: F401

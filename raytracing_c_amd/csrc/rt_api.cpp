@@ -36,6 +36,7 @@ int rt_launch_resolve(int width, int height, int samples, int chunks_x, const in
                       hipStream_t stream);
 int rt_launch_untile(int width, int height, int chunks_x, int n_chunks, const int32_t *owner_slot,
                      const uint8_t *all_tiles, uint8_t *image, hipStream_t stream);
+#ifdef RT_DIAG_VARIANTS      // unit-test kernels and the wavefront pipeline exist in the diagnostic library only
 int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream);
 int rt_launch_test_rcp_sweep(unsigned long long *counts, hipStream_t stream);
 int rt_launch_test_srgb_sweep(unsigned long long *counts, hipStream_t stream);
@@ -46,16 +47,19 @@ int rt_launch_test_trace_stream(const RT_KParams *P, int n, const float *rays, c
                                 int smem_bytes, float *out_t, int *out_tri, float *out_uv, unsigned long long *visits,
                                 hipStream_t stream);
 int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const float *uv, float *out, hipStream_t stream);
+#endif
 int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int lw, int lh, int stride, int comp,
                        int samples, int *owner, uint8_t *pixels, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
 int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
                            hipStream_t stream);
+#ifdef RT_DIAG_VARIANTS
 // rt_wavefront.hip
 int rt_wf_launch_camera(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream);
 int rt_wf_launch_trace(const RT_KParams *P, int n_blocks, int geometry, int smem_bytes, hipStream_t stream);
 int rt_wf_launch_shade(const RT_KParams *P, int n_blocks, int first, hipStream_t stream);
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -159,8 +163,9 @@ extern "C" int rt_set_devices(i32 n_devices, i32 rehearse) {
   return 0;
 }
 
-// 0 = tile-stream path kernel (the product's kernel), 1 = wavefront pipeline (rt_wavefront.hip: same images and counters,
-// measured slower -- kept selectable for measurements and for its queue-driven trace kernel)
+#ifdef RT_DIAG_VARIANTS
+// Diagnostic library only.  0 = tile-stream path kernel (the product's ONE kernel), 1 = wavefront pipeline (rt_wavefront.hip:
+// same images and counters, measured slower on every BASELINE config -- profiles/r03_experiments.md -- kept for measurements)
 static std::atomic<int>     g_pipeline{0};
 static std::atomic<int64_t> g_wf_cap_records{(int64_t)96 << 20};
 
@@ -173,6 +178,7 @@ extern "C" i32 rt_get_pipeline(void) { return g_pipeline.load(); }
 extern "C" void rt_set_wavefront_capacity(i64 records) {
   if (records >= 1024) g_wf_cap_records.store(records);
 }
+#endif
 
 // ---------------------------------------------------------------------------------
 // per-device state
@@ -316,6 +322,21 @@ extern "C" Color3 sample_background(Image const *, Vec3) {
   c.x = c.y = c.z = 0.0f;
   return c;
 }
+
+// What rt_scene_upload compares Shader.proc / Background.proc with: this library's own exported tokens.  The diagnostic
+// library can be told to recognise the PRODUCT library's tokens instead (rt_diag_set_tokens): a test process that has both
+// libraries mapped builds its scenes once, with the product's addresses, and sends them through the unit-test entry points
+// of the diagnostic build.
+static Shader_Proc     g_tok_disney = disney_shader_proc;
+static Shader_Proc     g_tok_debug = debug_shader_proc;
+static Background_Proc g_tok_background = (Background_Proc)sample_background;
+#ifdef RT_DIAG_VARIANTS
+extern "C" void rt_diag_set_tokens(void *disney, void *debug, void *background) {
+  if (disney) g_tok_disney = (Shader_Proc)disney;
+  if (debug) g_tok_debug = (Shader_Proc)debug;
+  if (background) g_tok_background = (Background_Proc)background;
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // scene residency
@@ -533,7 +554,7 @@ static uint64_t scene_fingerprint(Scene const *scene) {
       for (const void *q : seen) if (q == sh.data) { dup = true; break; }
       if (dup) continue;
       seen.push_back(sh.data);
-      if (sh.proc == disney_shader_proc || sh.proc == debug_shader_proc) {
+      if (sh.proc == g_tok_disney || sh.proc == g_tok_debug) {
         const PBR_Shader_Data *m = (const PBR_Shader_Data *)sh.data;
         h = hash_bytes(h, m, sizeof *m);
         h = hash_image(h, m->texture_albedo);
@@ -544,7 +565,7 @@ static uint64_t scene_fingerprint(Scene const *scene) {
       if (seen.size() > 4096) break;             // pathological material counts: the pointers are in the AoS hash anyway
     }
   }
-  if (scene->background.proc == (Background_Proc)sample_background) h = hash_image(h, (Image const *)scene->background.data);
+  if (scene->background.proc == g_tok_background) h = hash_image(h, (Image const *)scene->background.data);
   return h;
 }
 
@@ -606,7 +627,7 @@ static uint64_t scene_stamp(Scene const *scene, const std::vector<const void *> 
       h = hash_image_desc(h, m->texture_metal_roughness);
       h = hash_image_desc(h, m->texture_emission);
     }
-  if (scene->background.proc == (Background_Proc)sample_background) h = hash_image_desc(h, (Image const *)scene->background.data);
+  if (scene->background.proc == g_tok_background) h = hash_image_desc(h, (Image const *)scene->background.data);
   return h | 1ull;
 }
 
@@ -638,7 +659,7 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
       return nullptr;
     }
   }
-  if (scene->background.proc != (Background_Proc)sample_background || !scene->background.data) {
+  if (scene->background.proc != g_tok_background || !scene->background.data) {
     rt_fail("rt_scene_upload: background.proc is not the exported sample_background token "
             "(host callbacks cannot run on the GPU)");
     return nullptr;
@@ -660,8 +681,8 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
       mat = -1;   // unpopulated slot: never hit (all-zero triangle)
     } else {
       int kind;
-      if (a.shader.proc == disney_shader_proc) kind = RT_MAT_DISNEY;
-      else if (a.shader.proc == debug_shader_proc) kind = RT_MAT_DEBUG;
+      if (a.shader.proc == g_tok_disney) kind = RT_MAT_DISNEY;
+      else if (a.shader.proc == g_tok_debug) kind = RT_MAT_DEBUG;
       else {
         rt_fail("rt_scene_upload: triangle %d uses a shader proc that is not an exported device material "
                 "(disney_shader_proc / debug_shader_proc)", i);
@@ -833,7 +854,19 @@ extern "C" int rt_scene_verify(Scene const *scene) {
   return 0;
 }
 
-static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d);
+static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
+  memset(K, 0, sizeof *K);
+  K->nodes = d->nodes;
+  K->leaves = d->leaves;
+  K->tris = d->tris;
+  K->mats = d->mats;
+  K->textures = d->textures;
+  K->texels = d->texels;
+  K->depth = d->depth;
+  K->last_row_offset = d->last_row_offset;
+  K->bg_texture = d->bg_texture;
+  K->n_nodes = d->n_nodes;
+}
 
 static RT_Device_Scene *cached_scene_locked(Device &D, Scene const *scene, float *stamp_ms, float *upload_ms) {
   if (!scene) { rt_fail("render: scene is NULL"); return nullptr; }
@@ -1080,7 +1113,8 @@ static int fill_kparams(Device &D, RT_KParams *K, RT_Device_Scene *d, Camera con
   return 0;
 }
 
-// ---- wavefront pipeline (rt_wavefront.hip) --------------------------------------------------------------------------
+#ifdef RT_DIAG_VARIANTS
+// ---- wavefront pipeline (rt_wavefront.hip; diagnostic library only) --------------------------------------------------
 // Camera kernel -> (shade, trace) per bounce, joined by record queues in HBM.  The queues are sized for `cap` camera-ray
 // hits per pass (grown on demand, never beyond rt_set_wavefront_capacity() records); a frame with more first hits than
 // that takes several passes: the camera kernel stops taking units when its hit queue is nearly full, the bounces run, and
@@ -1186,6 +1220,8 @@ static int launch_wavefront(Device &D, RT_Device_Scene *d, RT_KParams &K, hipStr
   return 0;
 }
 
+#endif  // RT_DIAG_VARIANTS
+
 // Enqueues one launch of the path tracer for p's rank / sample range.  D.mutex held, D's GPU current.
 // ev_prep (optional): recorded between the per-launch preparation and the path kernel.
 static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p, void *d_accum,
@@ -1200,9 +1236,10 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
   // 5 = the tile-stream kernel (the product's only generation); 1-4 exist in the diagnostic build
   int variant = knob_int("RT_KERNEL", 5);
   if (variant < 1 || variant > 5) variant = 5;
-  int pipeline = g_pipeline.load();
-  if (knob_is("RT_PIPELINE", "wf")) pipeline = 1;
-  if (variant != 5) pipeline = 0;
+  bool wavefront = false;
+#ifdef RT_DIAG_VARIANTS
+  wavefront = (g_pipeline.load() == 1 || knob_is("RT_PIPELINE", "wf")) && variant == 5;
+#endif
 
   // persistent grid: 16 waves per CU (4 per SIMD at <= 128 VGPRs), never more waves than work items
   int waves_per_cu = knob_int("RT_WAVES_PER_CU", 16);
@@ -1316,7 +1353,7 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     if (knob_int("RT_SHORT_DIV", 1) == 0) K.short_div = 0;
     // hits parked until a dense shade block can be made of them: 18 x 128 dwords per wave
     K.park = nullptr;
-    if (pipeline == 0 && knob_int("RT_PARK", 1) != 0 && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
+    if (!wavefront && knob_int("RT_PARK", 1) != 0 && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
       const int grid_waves = (n_waves + 15) / 16 * 16;         // whole workgroups of 16 waves are launched
       if (d->park_waves < grid_waves) {
         (void)hipFree(d->park);
@@ -1356,9 +1393,12 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     D.ws.ev1.push_back(b);
   }
   HIP_TRY(hipEventRecord(D.ws.ev0[slot], stream));
-  if (pipeline == 1) {
+#ifdef RT_DIAG_VARIANTS
+  if (wavefront) {
     if (launch_wavefront(D, d, K, stream) != 0) return -1;
-  } else {
+  } else
+#endif
+  {
     int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, stream);
     if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   }
@@ -1678,6 +1718,7 @@ static float timed_slot_ms(Workspace &W, size_t slot) {
   return event_ms(W.ev0[slot], W.ev1[slot]);
 }
 
+#ifdef RT_DIAG_VARIANTS
 // Block statistics of the diagnostic kernel (RT_KERNEL=4): 8 pairs (executions, lanes) for
 // shade, environment, regenerate, leaf-scalar, leaf-vector, node-scalar, node-vector, pop.
 extern "C" int rt_get_sched_stats(u64 out[32]) {
@@ -1700,6 +1741,7 @@ extern "C" int rt_get_wave_times(u64 *out, i32 max_waves) {
   HIP_TRY(hipMemcpy(out, D.ws.wave_times, (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
   return n;
 }
+#endif  // RT_DIAG_VARIANTS
 
 extern "C" f32 rt_last_kernel_ms(void) {
   Device &D = dev0();
@@ -1892,8 +1934,9 @@ extern "C" void denoise_image(Image const *src, Image const *dst, isize n_thread
 }
 
 
+#ifdef RT_DIAG_VARIANTS
 // ---------------------------------------------------------------------------------
-// unit-level device entry points
+// unit-level device entry points (include/rt_hip_diag.h; diagnostic library only)
 
 extern "C" int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out) {
   Device &D = dev0();
@@ -1968,19 +2011,6 @@ extern "C" int rt_test_tile_order(i32 n_tiles, u32 const *cost, u32 *order) {
   return 0;
 }
 
-static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
-  memset(K, 0, sizeof *K);
-  K->nodes = d->nodes;
-  K->leaves = d->leaves;
-  K->tris = d->tris;
-  K->mats = d->mats;
-  K->textures = d->textures;
-  K->texels = d->texels;
-  K->depth = d->depth;
-  K->last_row_offset = d->last_row_offset;
-  K->bg_texture = d->bg_texture;
-  K->n_nodes = d->n_nodes;
-}
 
 extern "C" int rt_test_trace(RT_Device_Scene *d, i32 n, f32 const *rays, f32 *out_t, i32 *out_tri, f32 *out_uv) {
   if (!d || n <= 0 || !rays || !out_t || !out_tri || !out_uv) return rt_fail("rt_test_trace: bad arguments");
@@ -2081,3 +2111,4 @@ extern "C" int rt_test_texture(RT_Device_Scene *d, i32 tex, i32 n, f32 const *uv
   if (rc != 0) return rt_fail("rt_test_texture failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
+#endif  // RT_DIAG_VARIANTS

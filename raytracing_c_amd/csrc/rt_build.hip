@@ -219,9 +219,9 @@ __global__ void leaf_insert_kernel(int n, const Triangle *tris, const uint32_t *
   float d = du1 * dv2 - du2 * dv1;
   if (rt_absf(d) < 0.0001f) d = (d < 0) ? -0.0001f : 0.0001f;
   float inv_d = 1.0f / d;
-  rt_v3 tangent = rt_v3_normalize(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge1, dv2), rt_v3_scale(edge2, dv1)), inv_d));
-  rt_v3 bitangent = rt_v3_normalize(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge2, du1), rt_v3_scale(edge1, du2)), inv_d));
-  rt_v3 fn = rt_v3_normalize(rt_v3_cross(edge1, edge2));
+  rt_v3 tangent = rt_v3_normalize_plain(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge1, dv2), rt_v3_scale(edge2, dv1)), inv_d));
+  rt_v3 bitangent = rt_v3_normalize_plain(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge2, du1), rt_v3_scale(edge1, du2)), inv_d));
+  rt_v3 fn = rt_v3_normalize_plain(rt_v3_cross_plain(edge1, edge2));
   aos->shader = t.shader;
   aos->normal.x = fn.x; aos->normal.y = fn.y; aos->normal.z = fn.z;
   aos->normal_a = t.normals[0];

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(DN_TX * DN_TY) void rt_denoise_kernel(int width, in
     const uint32_t wo = tile[centre], wm = pk[4];
     float o_r = (float)(int)(wo & 255u) * k, o_g = (float)(int)((wo >> 8) & 255u) * k, o_b = (float)(int)(wo >> 16) * k;
     float m_r = (float)(int)(wm & 255u) * k, m_g = (float)(int)((wm >> 8) & 255u) * k, m_b = (float)(int)(wm >> 16) * k;
-    uint32_t q0 = (uint8_t)(rt_lerpf(o_r, m_r, diff) * 255.999f);
-    uint32_t q1 = (uint8_t)(rt_lerpf(o_g, m_g, diff) * 255.999f);
-    uint32_t q2 = (uint8_t)(rt_lerpf(o_b, m_b, diff) * 255.999f);
+    uint32_t q0 = (uint8_t)(rt_lerpf_plain(o_r, m_r, diff) * 255.999f);
+    uint32_t q1 = (uint8_t)(rt_lerpf_plain(o_g, m_g, diff) * 255.999f);
+    uint32_t q2 = (uint8_t)(rt_lerpf_plain(o_b, m_b, diff) * 255.999f);
     rgb = q0 | (q1 << 8) | (q2 << 16);
   }
   if (dword_out) {

@@ -43,8 +43,14 @@
 struct Ray3 {
   rt_v3 o, d;
   float inv_x, inv_y, inv_z;
-  bool  fast;     // origin and reciprocal direction all finite: NaN-free slab arithmetic
+  bool  fast;     // rt_slab_fast(): reciprocal direction and slab bias -(o * inv) all finite: NaN-free slab arithmetic
 };
+
+// The slab biases -(o * inv) of numeric contract v2 (rt_math.h): recomputed where a block needs them (three
+// multiplications per block) instead of kept in three more registers per lane across the whole loop.
+__device__ __forceinline__ rt_v3 slab_bias3(const Ray3 &r) {
+  return rt_v3_make(rt_slab_bias(r.o.x, r.inv_x), rt_slab_bias(r.o.y, r.inv_y), rt_slab_bias(r.o.z, r.inv_z));
+}
 
 struct HitRec {
   float t;
@@ -74,23 +80,24 @@ __device__ __forceinline__ int   as_i(float f) { return __float_as_int(f); }
 // Slab tests.  Two code paths with identical results wherever both are defined:
 //  * EXACT reproduces the operand order and the NaN behaviour of _mm256_min_ps /
 //    _mm256_max_ps in raytracer.c:209-228 with compare+select;
-//  * FAST uses v_min_f32 / v_max3_f32.  It is taken only for rays whose origin and
-//    reciprocal direction are all finite (Ray3::fast): then no NaN can appear in
-//    the slab arithmetic, and on NaN-free operands min/max are plain min/max, so
-//    both paths return the same bits (sign of zero cannot matter: every distance
-//    is clamped to >= EPSILON before it is used).  Axis-aligned rays (0 * inf)
+//  * FAST uses v_min_f32 / v_max3_f32, and under numeric contract v2 (rt_math.h) takes every plane
+//    distance from one fused multiply-add, fma(plane, inv, -(o * inv)) -- the oracle does the same for
+//    the same rays (rt_slab_fast / rt_slab_t_fast are shared).  It is taken only for rays whose
+//    reciprocal direction and slab bias are all finite (Ray3::fast): then no NaN can appear in
+//    the slab arithmetic, and on NaN-free operands min/max are plain min/max (sign of zero cannot
+//    matter: every distance is clamped to >= EPSILON before it is used).  Axis-aligned rays (0 * inf)
 //    take the EXACT path; tests/test_gpu_parity.py sends such rays.
 
 __device__ __forceinline__ float fmin_hw(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float fmax_hw(float a, float b) { return __builtin_fmaxf(a, b); }
 
 template <bool FAST>
-__device__ __forceinline__ float slab_entry(const Ray3 &r, float mnx, float mny, float mnz,
+__device__ __forceinline__ float slab_entry(const Ray3 &r, const rt_v3 &bs, float mnx, float mny, float mnz,
                                             float mxx, float mxy, float mxz, float t_max) {
-  float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
-  float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
-  float t0z = (mnz - r.o.z) * r.inv_z, t1z = (mxz - r.o.z) * r.inv_z;
   if (FAST) {
+    float t0x = rt_slab_t_fast(mnx, r.o.x, r.inv_x, bs.x), t1x = rt_slab_t_fast(mxx, r.o.x, r.inv_x, bs.x);
+    float t0y = rt_slab_t_fast(mny, r.o.y, r.inv_y, bs.y), t1y = rt_slab_t_fast(mxy, r.o.y, r.inv_y, bs.y);
+    float t0z = rt_slab_t_fast(mnz, r.o.z, r.inv_z, bs.z), t1z = rt_slab_t_fast(mxz, r.o.z, r.inv_z, bs.z);
     float sx = fmin_hw(t0x, t1x), sy = fmin_hw(t0y, t1y), sz = fmin_hw(t0z, t1z);
     float bx = fmax_hw(t0x, t1x), by = fmax_hw(t0y, t1y), bz = fmax_hw(t0z, t1z);
     float t_minv = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
@@ -98,6 +105,19 @@ __device__ __forceinline__ float slab_entry(const Ray3 &r, float mnx, float mny,
     // t_maxv <= t_max, so "entry < exit" already implies the candidate test entry < t_max
     return (t_minv < t_maxv) ? t_minv : RT_INF;
   } else {
+    // a block that holds ONE ray that is not NaN-free runs this instantiation for all its lanes: every lane takes the
+    // plane distances in the form ITS ray is entitled to (they round differently under contract v2); min / max in the
+    // reference's operand order are plain min / max on the NaN-free ones
+    float t0x, t1x, t0y, t1y, t0z, t1z;
+    if (r.fast) {
+      t0x = rt_slab_t_fast(mnx, r.o.x, r.inv_x, bs.x); t1x = rt_slab_t_fast(mxx, r.o.x, r.inv_x, bs.x);
+      t0y = rt_slab_t_fast(mny, r.o.y, r.inv_y, bs.y); t1y = rt_slab_t_fast(mxy, r.o.y, r.inv_y, bs.y);
+      t0z = rt_slab_t_fast(mnz, r.o.z, r.inv_z, bs.z); t1z = rt_slab_t_fast(mxz, r.o.z, r.inv_z, bs.z);
+    } else {
+      t0x = rt_slab_t_exact(mnx, r.o.x, r.inv_x); t1x = rt_slab_t_exact(mxx, r.o.x, r.inv_x);
+      t0y = rt_slab_t_exact(mny, r.o.y, r.inv_y); t1y = rt_slab_t_exact(mxy, r.o.y, r.inv_y);
+      t0z = rt_slab_t_exact(mnz, r.o.z, r.inv_z); t1z = rt_slab_t_exact(mxz, r.o.z, r.inv_z);
+    }
     float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
     float bx = rt_max_ps(t0x, t1x), by = rt_max_ps(t0y, t1y), bz = rt_max_ps(t0z, t1z);
     float t_minv = rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
@@ -109,13 +129,23 @@ __device__ __forceinline__ float slab_entry(const Ray3 &r, float mnx, float mny,
 
 // Entry distance of child j only; the miss test against t_max was already passed
 // when the node was entered, so only t_minv is needed (see header comment).
+// (called per lane: a FAST instantiation must only see rays with Ray3::fast, the other one takes the form the ray's
+// own `fast` flag selects -- the two forms differ in their rounding under contract v2)
 template <bool FAST>
 __device__ __forceinline__ float slab_entry_child(const float *n, const Ray3 &r) {
   // n -> element j of the node's first row; the six rows are 8 floats apart
   float mnx = n[0], mny = n[8], mnz = n[16], mxx = n[24], mxy = n[32], mxz = n[40];
-  float t0x = (mnx - r.o.x) * r.inv_x, t1x = (mxx - r.o.x) * r.inv_x;
-  float t0y = (mny - r.o.y) * r.inv_y, t1y = (mxy - r.o.y) * r.inv_y;
-  float t0z = (mnz - r.o.z) * r.inv_z, t1z = (mxz - r.o.z) * r.inv_z;
+  float t0x, t1x, t0y, t1y, t0z, t1z;
+  if (FAST || r.fast) {
+    const rt_v3 bs = slab_bias3(r);
+    t0x = rt_slab_t_fast(mnx, r.o.x, r.inv_x, bs.x); t1x = rt_slab_t_fast(mxx, r.o.x, r.inv_x, bs.x);
+    t0y = rt_slab_t_fast(mny, r.o.y, r.inv_y, bs.y); t1y = rt_slab_t_fast(mxy, r.o.y, r.inv_y, bs.y);
+    t0z = rt_slab_t_fast(mnz, r.o.z, r.inv_z, bs.z); t1z = rt_slab_t_fast(mxz, r.o.z, r.inv_z, bs.z);
+  } else {
+    t0x = rt_slab_t_exact(mnx, r.o.x, r.inv_x); t1x = rt_slab_t_exact(mxx, r.o.x, r.inv_x);
+    t0y = rt_slab_t_exact(mny, r.o.y, r.inv_y); t1y = rt_slab_t_exact(mxy, r.o.y, r.inv_y);
+    t0z = rt_slab_t_exact(mnz, r.o.z, r.inv_z); t1z = rt_slab_t_exact(mxz, r.o.z, r.inv_z);
+  }
   if (FAST) {
     float sx = fmin_hw(t0x, t1x), sy = fmin_hw(t0y, t1y), sz = fmin_hw(t0z, t1z);
     return fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
@@ -146,17 +176,18 @@ template <bool FAST, int MODE>
 __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t,
                                                const float4 *lds_nodes) {
   int d[8];
+  const rt_v3 bs = slab_bias3(r);
   if (MODE == NODE_SCALAR) {               // `node` is wave-uniform: node data lives in SGPRs
     cfloat *nb = as_scalar_ptr(P.nodes) + (size_t)node * 48;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      d[k] = as_i(slab_entry<FAST>(r, nb[k], nb[8 + k], nb[16 + k], nb[24 + k], nb[32 + k], nb[40 + k], hit_t));
+      d[k] = as_i(slab_entry<FAST>(r, bs, nb[k], nb[8 + k], nb[16 + k], nb[24 + k], nb[32 + k], nb[40 + k], hit_t));
     }
   } else if (FAST && MODE == NODE_LDS_ORDERED) {
     // Near and far plane of every slab picked by ADDRESS from the sign of the reciprocal direction instead of by min / max
-    // of the two products: with min <= max in every box (checked at upload, rt_api.cpp) and NaN-free operands,
-    // (mn - o) * inv <= (mx - o) * inv for inv > 0 and >= for inv < 0 -- rounding is monotonic -- so the picked product IS
-    // the minimum (maximum); for inv = 0 both are zero.  Six min / max fewer per child.
+    // of the two distances: with min <= max in every box (checked at upload, rt_api.cpp) and NaN-free operands,
+    // t(mn) <= t(mx) for inv > 0 and >= for inv < 0 -- rounding is monotonic, for (p - o) * inv and for fma(p, inv, bias)
+    // alike -- so the picked distance IS the minimum (maximum); for inv = 0 both are equal.  Six min / max fewer per child.
     const char *nbase = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node));
     const int nx = (as_i(r.inv_x) >> 31) & 96, ny = (as_i(r.inv_y) >> 31) & 96, nz = (as_i(r.inv_z) >> 31) & 96;   // bytes: min rows 0 / 32 / 64, max rows +96
 #pragma unroll
@@ -169,9 +200,9 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
       const float nzs[4] = {az.x, az.y, az.z, az.w}, fzs[4] = {bz.x, bz.y, bz.z, bz.w};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float sx = (nxs[k] - r.o.x) * r.inv_x, bxx = (fxs[k] - r.o.x) * r.inv_x;
-        const float sy = (nys[k] - r.o.y) * r.inv_y, byy = (fys[k] - r.o.y) * r.inv_y;
-        const float sz = (nzs[k] - r.o.z) * r.inv_z, bzz = (fzs[k] - r.o.z) * r.inv_z;
+        const float sx = rt_slab_t_fast(nxs[k], r.o.x, r.inv_x, bs.x), bxx = rt_slab_t_fast(fxs[k], r.o.x, r.inv_x, bs.x);
+        const float sy = rt_slab_t_fast(nys[k], r.o.y, r.inv_y, bs.y), byy = rt_slab_t_fast(fys[k], r.o.y, r.inv_y, bs.y);
+        const float sz = rt_slab_t_fast(nzs[k], r.o.z, r.inv_z, bs.z), bzz = rt_slab_t_fast(fzs[k], r.o.z, r.inv_z, bs.z);
         const float t_minv = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
         const float t_maxv = fmin_hw(hit_t, fmin_hw(bxx, fmin_hw(byy, bzz)));
         d[h * 4 + k] = as_i((t_minv < t_maxv) ? t_minv : RT_INF);
@@ -184,10 +215,10 @@ __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &
     for (int h = 0; h < 2; h++) {          // children 0-3, then 4-7: half the node in registers at a time
       float4 mnx = nb[0 + h], mny = nb[2 + h], mnz = nb[4 + h];
       float4 mxx = nb[6 + h], mxy = nb[8 + h], mxz = nb[10 + h];
-      d[h * 4 + 0] = as_i(slab_entry<FAST>(r, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, hit_t));
-      d[h * 4 + 1] = as_i(slab_entry<FAST>(r, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, hit_t));
-      d[h * 4 + 2] = as_i(slab_entry<FAST>(r, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, hit_t));
-      d[h * 4 + 3] = as_i(slab_entry<FAST>(r, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, hit_t));
+      d[h * 4 + 0] = as_i(slab_entry<FAST>(r, bs, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, hit_t));
+      d[h * 4 + 1] = as_i(slab_entry<FAST>(r, bs, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, hit_t));
+      d[h * 4 + 2] = as_i(slab_entry<FAST>(r, bs, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, hit_t));
+      d[h * 4 + 3] = as_i(slab_entry<FAST>(r, bs, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, hit_t));
     }
   }
 
@@ -575,8 +606,8 @@ template <class PT>
 __device__ __forceinline__ rt_v3 background_lookup(const PT &P, rt_v3 dir) {
   float inv_pi = 1.0f / RT_PI;
   float inv_two_pi = 1.0f / (2.0f * RT_PI);
-  float u = 0.5f + rt_atan2f(dir.z, dir.x) * inv_two_pi;
-  float v = 0.5f - rt_asinf(dir.y) * inv_pi;
+  float u = rt_madd(rt_atan2f(dir.z, dir.x), inv_two_pi, 0.5f);
+  float v = rt_madd(-rt_asinf(dir.y), inv_pi, 0.5f);
   return srgb_to_linear_tex(tex_bilinear(P, P.bg_texture, u, v));
 }
 
@@ -588,14 +619,14 @@ __device__ __forceinline__ float luminance(rt_v3 x) { return rt_v3_dot(x, rt_v3_
 
 __device__ __forceinline__ float ggx_D(float roughness, float NoH) {          // driver.c:212-215, k = 2
   float a2 = roughness * roughness;
-  float d = (NoH * NoH) * (a2 * a2 - 1.0f) + 1.0f;
+  float d = rt_madd(NoH * NoH, rt_madd(a2, a2, -1.0f), 1.0f);
   return a2 / (RT_PI * (d * d));
 }
 
 __device__ __forceinline__ float smith_G(float NDotV, float alpha2) {         // driver.c:217-221
   float a = alpha2 * alpha2;
   float b = NDotV * NDotV;
-  return (2.0f * NDotV) / (NDotV + rt_sqrtf(a + b - a * b));
+  return (2.0f * NDotV) / (NDotV + rt_sqrtf(rt_madd(-a, b, a + b)));
 }
 
 __device__ __forceinline__ rt_v3 cosine_hemisphere(uint32_t &rng) {           // driver.c:118-127
@@ -603,12 +634,12 @@ __device__ __forceinline__ rt_v3 cosine_hemisphere(uint32_t &rng) {           //
   float distance = rt_sqrtf(rt_rand_f32(&rng));
   float s, c;
   rt_sincosf(angle, &s, &c);
-  return rt_v3_make(s * distance, c * distance, rt_sqrtf(1.0f - distance * distance));
+  return rt_v3_make(s * distance, c * distance, rt_sqrtf(rt_madd(-distance, distance, 1.0f)));
 }
 
 __device__ __forceinline__ rt_v3 ggx_vndf(rt_v3 V, float ax, float ay, uint32_t &rng) {  // driver.c:230-250
   rt_v3 Vh = normalize_dev(rt_v3_make(ax * V.x, ay * V.y, V.z));
-  float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+  float lensq = rt_dot2(Vh.x, Vh.x, Vh.y, Vh.y);
   rt_v3 T1 = lensq > 0.0f ? rt_v3_scale(rt_v3_make(-Vh.y, Vh.x, 0.0f), rcp_exact(rt_sqrtf(lensq))) : rt_v3_make(1, 0, 0);
   rt_v3 T2 = rt_v3_cross(Vh, T1);
   float r = rt_sqrtf(rt_rand_f32(&rng));
@@ -617,10 +648,9 @@ __device__ __forceinline__ rt_v3 ggx_vndf(rt_v3 V, float ax, float ay, uint32_t 
   rt_sincosf(phi, &sn, &cs);
   float t1 = r * cs;
   float t2 = r * sn;
-  float s = 0.5f * (1.0f + Vh.z);
-  t2 = (1.0f - s) * rt_sqrtf(1.0f - t1 * t1) + s * t2;
-  rt_v3 Nh = rt_v3_add(rt_v3_add(rt_v3_scale(T1, t1), rt_v3_scale(T2, t2)),
-                       rt_v3_scale(Vh, rt_sqrtf(rt_max_ps(0.0f, 1.0f - t1 * t1 - t2 * t2))));
+  float s = rt_madd(0.5f, Vh.z, 0.5f);
+  t2 = rt_madd(1.0f - s, rt_sqrtf(rt_madd(-t1, t1, 1.0f)), s * t2);
+  rt_v3 Nh = rt_v3_comb3(T1, t1, T2, t2, Vh, rt_sqrtf(rt_max_ps(0.0f, rt_madd(-t2, t2, rt_madd(-t1, t1, 1.0f)))));
   return normalize_dev(rt_v3_make(ax * Nh.x, ay * Nh.y, rt_max_ps(0.0f, Nh.z)));
 }
 
@@ -639,7 +669,7 @@ __device__ __forceinline__ void sample_disney(const BrdfIn &m, rt_v3 in_dir, uin
   rt_v3 f0 = rt_v3_lerp(rt_v3_make(0.04f, 0.04f, 0.04f), m.base_color, m.metalness);
   float f90 = rt_min_ps(1.0f, (1.0f / 0.04f) * luminance(f0));
   float theta = rt_v3_dot(in_dir, micro);
-  rt_v3 fresnel = rt_v3_add(f0, rt_v3_scale(rt_v3_sub(rt_v3_make(f90, f90, f90), f0), pow5(1.0f - theta)));
+  rt_v3 fresnel = rt_v3_madd(rt_v3_sub(rt_v3_make(f90, f90, f90), f0), pow5(1.0f - theta), f0);
 
   float dw = 1.0f - m.metalness;
   float sw = luminance(fresnel);
@@ -657,9 +687,9 @@ __device__ __forceinline__ void sample_disney(const BrdfIn &m, rt_v3 in_dir, uin
     if (NoL <= 0.0f || NoV <= 0.0f) return;
     float LoH = rt_v3_dot(out_dir, micro);
     float pdf = NoL / RT_PI;
-    float FD90 = 0.5f + 2.0f * m.roughness * LoH * LoH;
-    float fa = 1.0f + (FD90 - 1.0f) * pow5(1.0f - NoL);
-    float fb = 1.0f + (FD90 - 1.0f) * pow5(1.0f - NoV);
+    float FD90 = rt_madd(2.0f * m.roughness * LoH, LoH, 0.5f);
+    float fa = rt_madd(FD90 - 1.0f, pow5(1.0f - NoL), 1.0f);
+    float fb = rt_madd(FD90 - 1.0f, pow5(1.0f - NoV), 1.0f);
     rt_v3 diff = rt_v3_mul(rt_v3_scale(m.base_color, (fa * fb / RT_PI)), rt_v3_sub(rt_v3_make(1, 1, 1), fresnel));
     rt_v3 sheen = rt_v3_make(0, 0, 0);
     if (m.sheen > 0.0f) {                                                     // driver.c:166-183
@@ -700,13 +730,13 @@ __device__ __forceinline__ rt_v3 normal_map(const PT &P, int tex, float strength
   rt_v3 normal = in.normal;
   if (tex >= 0) {
     rt_v3 v = tex_bilinear(P, tex, in.uvx, in.uvy);
-    v = rt_v3_add(rt_v3_scale(v, 2.0f), rt_v3_make(-1.0f, -1.0f, -1.0f));
+    v = rt_v3_madd(v, 2.0f, rt_v3_make(-1.0f, -1.0f, -1.0f));
     v.y *= -1.0f;
     rt_v3 t = in.tangent, b = in.bitangent, n = in.normal;
     float s = strength;
-    normal = normalize_dev(rt_v3_make(s * (v.x * t.x + v.y * b.x + v.z * n.x) + n.x * (1.0f - s),
-                                        s * (v.x * t.y + v.y * b.y + v.z * n.y) + n.y * (1.0f - s),
-                                        s * (v.x * t.z + v.y * b.z + v.z * n.z) + n.z * (1.0f - s)));
+    normal = normalize_dev(rt_v3_make(rt_madd(s, rt_dot3(v.x, t.x, v.y, b.x, v.z, n.x), n.x * (1.0f - s)),
+                                        rt_madd(s, rt_dot3(v.x, t.y, v.y, b.y, v.z, n.y), n.y * (1.0f - s)),
+                                        rt_madd(s, rt_dot3(v.x, t.z, v.y, b.z, v.z, n.z), n.z * (1.0f - s))));
   }
   return normal;
 }
@@ -744,7 +774,7 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   out_dir = rt_v3_make(0, 0, 0);
 
   if (kind == RT_MAT_DEBUG) {
-    emission = rt_v3_add(rt_v3_scale(normal, 0.5f), rt_v3_make(0.5f, 0.5f, 0.5f));
+    emission = rt_v3_madd(normal, 0.5f, rt_v3_make(0.5f, 0.5f, 0.5f));
     terminate = true;
     return;
   }
@@ -792,9 +822,7 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   float a;
   sample_disney(bi, in_dir, rng, o, rgb, a);
 
-  out_dir = rt_v3_make(t.x * o.x + b.x * o.y + normal.x * o.z,
-                       t.y * o.x + b.y * o.y + normal.y * o.z,
-                       t.z * o.x + b.z * o.y + normal.z * o.z);
+  out_dir = rt_v3_comb3(t, o.x, b, o.y, normal, o.z);
   if (a > 0.0f) {
     tint = rt_v3_make(rgb.x / a, rgb.y / a, rgb.z / a);
   } else {
@@ -812,14 +840,14 @@ __device__ __forceinline__ void primary_ray(const PT &P, int x, int y, int sampl
   float inv_height = P.inv_height;
   float aspect = P.aspect;
   float jitter = rt_hash12((float)x * 50.0f + (float)sample, (float)y);
-  float uvx = ((float)x + jitter - 0.5f) * 2.0f * inv_width - 1.0f;
-  float uvy = ((float)y + jitter - 0.5f) * 2.0f * inv_height - 1.0f;
+  float uvx = rt_madd(((float)x + jitter - 0.5f) * 2.0f, inv_width, -1.0f);
+  float uvy = rt_madd(((float)y + jitter - 0.5f) * 2.0f, inv_height, -1.0f);
   float dx = uvx * aspect, dy = -uvy, dz = -P.focal_length;
   // (rcp_exact: a square root lies in [0, 2^64] or is infinite / NaN -- inside the domain on which it equals the division)
-  float inv_length = rcp_exact(rt_sqrtf(dx * dx + dy * dy + dz * dz));
-  float rx = P.cam[0][0] * dx + P.cam[0][1] * dy + P.cam[0][2] * dz;
-  float ry = P.cam[1][0] * dx + P.cam[1][1] * dy + P.cam[1][2] * dz;
-  float rz = P.cam[2][0] * dx + P.cam[2][1] * dy + P.cam[2][2] * dz;
+  float inv_length = rcp_exact(rt_sqrtf(rt_dot3(dx, dx, dy, dy, dz, dz)));
+  float rx = rt_dot3(P.cam[0][0], dx, P.cam[0][1], dy, P.cam[0][2], dz);
+  float ry = rt_dot3(P.cam[1][0], dx, P.cam[1][1], dy, P.cam[1][2], dz);
+  float rz = rt_dot3(P.cam[2][0], dx, P.cam[2][1], dy, P.cam[2][2], dz);
   o = rt_v3_make(P.cam[0][3], P.cam[1][3], P.cam[2][3]);
   d = rt_v3_make(rx * inv_length, ry * inv_length, rz * inv_length);
 }
@@ -841,8 +869,7 @@ __device__ __forceinline__ void ray_setup(Ray3 &r, rt_v3 o, rt_v3 d) {
     r.inv_y = 1.0f / d.y;
     r.inv_z = 1.0f / d.z;
   }
-  r.fast = (rt_absf(r.inv_x) < RT_INF) && (rt_absf(r.inv_y) < RT_INF) && (rt_absf(r.inv_z) < RT_INF) &&
-           (rt_absf(o.x) < RT_INF) && (rt_absf(o.y) < RT_INF) && (rt_absf(o.z) < RT_INF);
+  r.fast = rt_slab_fast(r.inv_x, r.inv_y, r.inv_z, rt_slab_bias(o.x, r.inv_x), rt_slab_bias(o.y, r.inv_y), rt_slab_bias(o.z, r.inv_z));
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -863,27 +890,27 @@ __device__ __forceinline__ bool shade_hit(const PT &P, const HitRec &hit, rt_v3 
   float4 q4 = ld4(tb, 4), q5 = ld4(tb, 5), q6 = ld4(tb, 6);
   float t1 = hit.u, t2 = hit.v;
   float t0 = 1.0f - t1 - t2;
-  rt_v3 point = rt_v3_add(org, rt_v3_scale(dir, hit.t));
+  rt_v3 point = rt_v3_madd(dir, hit.t, org);
   rt_v3 n_geo = rt_v3_make(q0.x, q0.y, q0.z);
-  rt_v3 n_int = rt_v3_make(q1.x * t0 + q2.x * t1 + q3.x * t2,
-                           q1.y * t0 + q2.y * t1 + q3.y * t2,
-                           q1.z * t0 + q2.z * t1 + q3.z * t2);
+  rt_v3 n_int = rt_v3_make(rt_dot3(q1.x, t0, q2.x, t1, q3.x, t2),
+                           rt_dot3(q1.y, t0, q2.y, t1, q3.y, t2),
+                           rt_dot3(q1.z, t0, q2.z, t1, q3.z, t2));
   if (rt_v3_dot(n_geo, dir) > 0.0f || rt_v3_dot(n_int, dir) > 0.0f) {
     // back face: pass through, costs a bounce (raytracer.c:516-522)
-    org = rt_v3_add(point, rt_v3_scale(dir, RT_EPS));
+    org = rt_v3_madd(dir, RT_EPS, point);
   } else {
     ShadeIn in;
     in.direction = dir;
     in.normal = normalize_dev(n_int);
     in.tangent = rt_v3_make(q4.x, q4.y, q4.z);
     in.bitangent = rt_v3_make(q5.x, q5.y, q5.z);
-    in.uvx = q1.w * t0 + q3.w * t1 + q5.w * t2;
-    in.uvy = q2.w * t0 + q4.w * t1 + q6.x * t2;
+    in.uvx = rt_dot3(q1.w, t0, q3.w, t1, q5.w, t2);
+    in.uvy = rt_dot3(q2.w, t0, q4.w, t1, q6.x, t2);
     rt_v3 out_dir, s_tint, s_emis;
     bool terminate;
     cn.shades += 1;
     shade(P, as_i(q0.w), in, rng, out_dir, s_tint, s_emis, terminate, cn);
-    emis = rt_v3_add(emis, rt_v3_mul(s_emis, tint));
+    emis = rt_v3_mul_add(s_emis, tint, emis);
     if (terminate) {
       done = true;
       radiance = emis;
@@ -892,7 +919,7 @@ __device__ __forceinline__ bool shade_hit(const PT &P, const HitRec &hit, rt_v3 
       tint = rt_v3_mul(tint, s_tint);
       float below = (rt_v3_dot(n_geo, out_dir) < 0.0f) ? 1.0f : 0.0f;
       float bias = (0.5f - below) * 2.0f * RT_EPS;
-      org = rt_v3_add(point, rt_v3_scale(n_geo, bias));
+      org = rt_v3_madd(n_geo, bias, point);
     }
   }
   if (!done) {
@@ -963,20 +990,24 @@ __device__ __forceinline__ uint32_t pyramid_cull_mask(const float4 *lds_nodes, c
   const float loz = nz * (mnz - oz), hiz = nz * (mxz - oz);
   const float nearest = fminf(lox, hix) + fminf(loy, hiy) + fminf(loz, hiz);       // smallest n . (p - o) over the box
   const float extent = fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz));
-  const bool outside = empty || nearest > 1e-3f * extent;                           // (NaN compares false: not outside)
+  // contract v2: a fused slab distance fma(p, inv, -(o * inv)) is off by up to an ulp of max(|p|, |o|) * |inv|, i.e. it
+  // places the plane within ~2^-23 max(|p|, |o|) of where it is; the margin carries 8 times that, in units of n . (p - o)
+  const float coarse = fabsf(nx) * (fabsf(ox) + fmaxf(fabsf(mnx), fabsf(mxx))) + fabsf(ny) * (fabsf(oy) + fmaxf(fabsf(mny), fabsf(mxy))) +
+                       fabsf(nz) * (fabsf(oz) + fmaxf(fabsf(mnz), fabsf(mxz)));
+  const bool outside = empty || nearest > 1e-3f * extent + 1e-6f * coarse;          // (NaN compares false: not outside)
   const uint32_t m = (uint32_t)__ballot(outside);                                  // lanes 0..31: 4 planes x 8 children
   return (m | (m >> 8) | (m >> 16) | (m >> 24)) & 0xFFu;
 }
 
 // slab_entry<true>() of child k of an LDS node with the planes picked by address (see NODE_LDS_ORDERED)
-__device__ __forceinline__ float slab_entry_ordered(const Ray3 &r, const char *nbase, int k, int nx, int ny, int nz, float t_max) {
+__device__ __forceinline__ float slab_entry_ordered(const Ray3 &r, const rt_v3 &bs, const char *nbase, int k, int nx, int ny, int nz, float t_max) {
   const char *b = nbase + k * 4;
-  const float sx = (*reinterpret_cast<const float *>(b + nx) - r.o.x) * r.inv_x;
-  const float bx = (*reinterpret_cast<const float *>(b + (96 - nx)) - r.o.x) * r.inv_x;
-  const float sy = (*reinterpret_cast<const float *>(b + 32 + ny) - r.o.y) * r.inv_y;
-  const float by = (*reinterpret_cast<const float *>(b + 32 + (96 - ny)) - r.o.y) * r.inv_y;
-  const float sz = (*reinterpret_cast<const float *>(b + 64 + nz) - r.o.z) * r.inv_z;
-  const float bz = (*reinterpret_cast<const float *>(b + 64 + (96 - nz)) - r.o.z) * r.inv_z;
+  const float sx = rt_slab_t_fast(*reinterpret_cast<const float *>(b + nx), r.o.x, r.inv_x, bs.x);
+  const float bx = rt_slab_t_fast(*reinterpret_cast<const float *>(b + (96 - nx)), r.o.x, r.inv_x, bs.x);
+  const float sy = rt_slab_t_fast(*reinterpret_cast<const float *>(b + 32 + ny), r.o.y, r.inv_y, bs.y);
+  const float by = rt_slab_t_fast(*reinterpret_cast<const float *>(b + 32 + (96 - ny)), r.o.y, r.inv_y, bs.y);
+  const float sz = rt_slab_t_fast(*reinterpret_cast<const float *>(b + 64 + nz), r.o.z, r.inv_z, bs.z);
+  const float bz = rt_slab_t_fast(*reinterpret_cast<const float *>(b + 64 + (96 - nz)), r.o.z, r.inv_z, bs.z);
   const float t_minv = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
   const float t_maxv = fmin_hw(t_max, fmin_hw(bx, fmin_hw(by, bz)));
   return (t_minv < t_maxv) ? t_minv : RT_INF;
@@ -988,14 +1019,15 @@ __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *
                                                    float hit_t) {
   const char *nbase = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node));
   const int nx = (as_i(r.inv_x) >> 31) & 96, ny = (as_i(r.inv_y) >> 31) & 96, nz = (as_i(r.inv_z) >> 31) & 96;
+  const rt_v3 bs = slab_bias3(r);
   const int n = (int)__popc(surv);
   const int k0 = (int)__builtin_ctz(surv);
-  const int e0 = as_i(slab_entry_ordered(r, nbase, k0, nx, ny, nz, hit_t));
+  const int e0 = as_i(slab_entry_ordered(r, bs, nbase, k0, nx, ny, nz, hit_t));
   const uint32_t f0 = 1u - (((uint32_t)e0 + 0x00800000u) >> 31);                   // 1 iff e0 is finite (a candidate)
   if (n == 1) return (uint32_t)k0 | (f0 << 24);
   surv &= surv - 1u;
   const int k1 = (int)__builtin_ctz(surv);
-  const int e1 = as_i(slab_entry_ordered(r, nbase, k1, nx, ny, nz, hit_t));
+  const int e1 = as_i(slab_entry_ordered(r, bs, nbase, k1, nx, ny, nz, hit_t));
   const uint32_t f1 = 1u - (((uint32_t)e1 + 0x00800000u) >> 31);
   if (n == 2) {
     const bool swap = e1 < e0;                                                     // ties: lowest index first
@@ -1004,14 +1036,14 @@ __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *
   }
   surv &= surv - 1u;
   const int k2 = (int)__builtin_ctz(surv);
-  const int e2 = as_i(slab_entry_ordered(r, nbase, k2, nx, ny, nz, hit_t));
+  const int e2 = as_i(slab_entry_ordered(r, bs, nbase, k2, nx, ny, nz, hit_t));
   const uint32_t f2 = 1u - (((uint32_t)e2 + 0x00800000u) >> 31);
   int e3 = 0x7F800000, k3 = 0;
   uint32_t f3 = 0;
   if (n == 4) {
     surv &= surv - 1u;
     k3 = (int)__builtin_ctz(surv);
-      e3 = as_i(slab_entry_ordered(r, nbase, k3, nx, ny, nz, hit_t));
+      e3 = as_i(slab_entry_ordered(r, bs, nbase, k3, nx, ny, nz, hit_t));
     f3 = 1u - (((uint32_t)e3 + 0x00800000u) >> 31);
   }
   const int e[4] = {e0, e1, e2, e3};
@@ -1173,9 +1205,10 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
               // entry distance from the three NEAR planes, picked by address (see NODE_LDS_ORDERED); the rays that are
               // not NaN-free -- a lane in a blue moon -- redo it through the min / max form
               const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
-              const float sx = (*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)) - ray.o.x) * ray.inv_x;
-              const float sy = (*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)) - ray.o.y) * ray.inv_y;
-              const float sz = (*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)) - ray.o.z) * ray.inv_z;
+              const rt_v3 bs = slab_bias3(ray);
+              const float sx = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)), ray.o.x, ray.inv_x, bs.x);
+              const float sy = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)), ray.o.y, ray.inv_y, bs.y);
+              const float sz = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)), ray.o.z, ray.inv_z, bs.z);
               dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
               if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
             } else {

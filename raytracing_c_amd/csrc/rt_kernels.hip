@@ -236,7 +236,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           float lox = n.x * lo.x, hix = n.x * hi.x, loy = n.y * lo.y, hiy = n.y * hi.y, loz = n.z * lo.z, hiz = n.z * hi.z;
           float nearest = fminf(lox, hix) + fminf(loy, hiy) + fminf(loz, hiz);     // smallest n . (p - o) over the box
           float extent = fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz));
-          if (nearest > 1e-3f * extent) outside = true;        // (NaN compares false: not outside)
+          // (+ the placement error of a fused slab distance, see pyramid_cull_mask)
+          float coarse = fabsf(n.x) * (fabsf(o.x) + fmaxf(fabsf(nb[0]), fabsf(nb[24]))) + fabsf(n.y) * (fabsf(o.y) + fmaxf(fabsf(nb[8]), fabsf(nb[32]))) +
+                         fabsf(n.z) * (fabsf(o.z) + fmaxf(fabsf(nb[16]), fabsf(nb[40])));
+          if (nearest > 1e-3f * extent + 1e-6f * coarse) outside = true;        // (NaN compares false: not outside)
         }
         may_hit = !outside;
       }
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         if (phase == PH_MISS) {
           cn.bgs = 1;
           rt_v3 bg = background_lookup(SP, dir);
-          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
+          radiance = rt_v3_mul_add(bg, tint, emis);
           done = true;
         }
         // ---- hits: shade them now, or park them until a dense shade block can be made of them ----
@@ -629,7 +632,7 @@ __device__ __forceinline__ rt_v3 cast_ray_lane(const RT_KParams &P, rt_v3 org, r
       done = shade_hit(P, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
     } else {
       cn.bgs += 1;
-      radiance = rt_v3_add(rt_v3_mul(background_lookup(P, dir), tint), emis);
+      radiance = rt_v3_mul_add(background_lookup(P, dir), tint, emis);
       done = true;
     }
   }
@@ -819,8 +822,11 @@ extern "C" int rt_launch_prepare(int n_tiles, uint32_t *tile_next, uint32_t *ope
   return (int)hipGetLastError();
 }
 
+#ifdef RT_DIAG_VARIANTS
 // ---------------------------------------------------------------------------------
-// unit-level kernels for parity tests
+// unit-level kernels for parity tests: compiled into the DIAGNOSTIC library only (librt_hip_diag.so, include/rt_hip_diag.h).
+// They instantiate the same device functions as the product's kernels (rt_dev.hip.h; traversal_blocks() is the path
+// kernel's own traversal); the product library carries no test entry point.
 
 __global__ void rt_test_math_kernel(int op, int n, const float *x, const float *y, float *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1026,6 +1032,7 @@ extern "C" int rt_launch_test_trace_stream(const RT_KParams *P, int n, const flo
 #undef RT_TTS
   return (int)hipGetLastError();
 }
+#endif  // RT_DIAG_VARIANTS (unit-level kernels)
 
 // ---------------------------------------------------------------------------------
 // launchers (called from rt_api.cpp)
@@ -1054,6 +1061,8 @@ extern "C" int rt_launch_path_kernel_diag(const RT_KParams *P, int n_waves, int 
 #ifndef RT_STREAM_MINW
 #define RT_STREAM_MINW 1     // (experiment builds: 5 caps the kernel at 96 VGPRs, 6 at 80 -- profiles/r03_experiments.md)
 #endif
+extern "C" int rt_math_contract(void) { return RT_MATH_CONTRACT; }      // include/rt_math.h: 2 = explicit FMA, 1 = -DRT_MATH_NO_FMA
+
 // variant 5 = the tile-stream kernel, the only path kernel of the product library; 1-4 exist in the diagnostic build only
 extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
 #ifdef RT_DIAG_VARIANTS
@@ -1099,6 +1108,7 @@ extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int height,
   return (int)hipGetLastError();
 }
 
+#ifdef RT_DIAG_VARIANTS
 extern "C" int rt_launch_test_math(int op, int n, const float *x, const float *y, float *out, hipStream_t stream) {
   hipLaunchKernelGGL(rt_test_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, n, x, y, out);
   return (int)hipGetLastError();
@@ -1131,3 +1141,4 @@ extern "C" int rt_launch_test_texture(const RT_KParams *P, int tex, int n, const
   hipLaunchKernelGGL(rt_test_texture_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *P, tex, n, uv, out);
   return (int)hipGetLastError();
 }
+#endif  // RT_DIAG_VARIANTS (unit-level launchers)

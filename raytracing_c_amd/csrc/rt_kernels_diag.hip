@@ -106,7 +106,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void rt_path_kernel(RT_KParams P)
         } else {
           cn.bgs += 1;
           rt_v3 bg = background_lookup(P, dir);
-          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
+          radiance = rt_v3_mul_add(bg, tint, emis);
           done = true;
         }
       }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           // ================= ENV: environment for the misses =================
           cn.bgs += 1;
           rt_v3 bg = background_lookup(P, dir);
-          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);
+          radiance = rt_v3_mul_add(bg, tint, emis);
           done = true;
         }
         if (done) {

@@ -102,12 +102,12 @@ static void triangles_insert(Triangles *triangles, Triangle const *v, isize coun
     if (rt_absf(d) < 0.0001f) d = (d < 0) ? -0.0001f : 0.0001f;
     f32 inv_d = 1.0f / d;
 
-    rt_v3 tangent   = rt_v3_normalize(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge1, dv2), rt_v3_scale(edge2, dv1)), inv_d));
-    rt_v3 bitangent = rt_v3_normalize(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge2, du1), rt_v3_scale(edge1, du2)), inv_d));
+    rt_v3 tangent   = rt_v3_normalize_plain(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge1, dv2), rt_v3_scale(edge2, dv1)), inv_d));
+    rt_v3 bitangent = rt_v3_normalize_plain(rt_v3_scale(rt_v3_sub(rt_v3_scale(edge2, du1), rt_v3_scale(edge1, du2)), inv_d));
 
     Triangle_AOS *aos = &triangles->aos[offset + i];
     aos->shader       = t->shader;
-    aos->normal       = Q(rt_v3_normalize(rt_v3_cross(edge1, edge2)));
+    aos->normal       = Q(rt_v3_normalize_plain(rt_v3_cross_plain(edge1, edge2)));
     aos->normal_a     = t->normals[0];
     aos->normal_b     = t->normals[1];
     aos->normal_c     = t->normals[2];

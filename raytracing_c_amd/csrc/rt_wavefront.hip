@@ -253,7 +253,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_wf_camera_k
           float lox = n.x * lo.x, hix = n.x * hi.x, loy = n.y * lo.y, hiy = n.y * hi.y, loz = n.z * lo.z, hiz = n.z * hi.z;
           float nearest = fminf(lox, hix) + fminf(loy, hiy) + fminf(loz, hiz);
           float extent = fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz));
-          if (nearest > 1e-3f * extent) outside = true;        // (NaN compares false: not outside)
+          // (+ the placement error of a fused slab distance, see pyramid_cull_mask)
+          float coarse = fabsf(n.x) * (fabsf(o.x) + fmaxf(fabsf(nb[0]), fabsf(nb[24]))) + fabsf(n.y) * (fabsf(o.y) + fmaxf(fabsf(nb[8]), fabsf(nb[32]))) +
+                         fabsf(n.z) * (fabsf(o.z) + fmaxf(fabsf(nb[16]), fabsf(nb[40])));
+          if (nearest > 1e-3f * extent + 1e-6f * coarse) outside = true;        // (NaN compares false: not outside)
         }
         may_hit = !outside;
       }
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_wf_trace_ke
           SP.tris = nullptr; SP.mats = nullptr; SP.textures = A->textures; SP.texels = A->texels;
           SP.bg_texture = A->bg_texture; SP.max_bounces = 0;
           const rt_v3 bg = background_lookup(SP, ray.d);
-          radiance = rt_v3_add(rt_v3_mul(bg, tint), emis);         // raytracer.c:554
+          radiance = rt_v3_mul_add(bg, tint, emis);         // raytracer.c:554
         }
         unsigned long long *frame = A->accum;
         if (frame) {

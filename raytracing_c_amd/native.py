@@ -11,6 +11,9 @@ from . import ctypes_abi as abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_LIB_PATH: A/B a differently built librt_hip.so (tools/exp_ab.sh); the default is the in-tree build.
 LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "librt_hip.so")
+# The diagnostic build (make diag): unit-test entry points (include/rt_hip_diag.h), the wavefront pipeline, the superseded
+# kernel generations.  Tests and experiments load it BESIDE the product library as `raytracing_c_amd.diag`.
+DIAG_PATH = os.path.join(_HERE, "librt_hip_diag.so")
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -50,19 +53,27 @@ def _preload_hip_runtime():
 class _Lazy:
     """Resolves the shared library on first attribute access."""
 
-    def __init__(self):
+    def __init__(self, path, diag=False):
         self._dll = None
+        self._path = path
+        self._diag = diag
 
     def _load(self):
         if self._dll is not None:
             return self._dll
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(self._path):
             raise NativeLibraryMissing(
-                f"{LIB_PATH} not found: build it with `make -C raytracing_c_amd/csrc` "
+                f"{self._path} not found: build it with `make -C raytracing_c_amd/csrc{' diag' if self._diag else ''}` "
                 "(or __graft_entry__.build()); there is no CPU fallback for the render path")
         _preload_hip_runtime()
-        dll = C.CDLL(LIB_PATH)
+        dll = C.CDLL(self._path)
         _declare(dll)
+        if self._diag or hasattr(dll, "rt_test_math"):
+            _declare_diag(dll)
+        if self._diag and os.path.realpath(self._path) != os.path.realpath(LIB_PATH):
+            # scenes are built with the PRODUCT library's material tokens (scene.py): make the diagnostic library accept them
+            dll.rt_diag_set_tokens(symbol_address("disney_shader_proc"), symbol_address("debug_shader_proc"),
+                                   symbol_address("sample_background"))
         self._dll = dll
         return dll
 
@@ -113,26 +124,13 @@ def _declare(d):
     d.rt_untile.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     d.rt_render_frame.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, vp, vp]
     d.rt_get_counters.argtypes = [P(abi.RT_Counters)]
-    d.rt_get_sched_stats.argtypes = [vp]
-    d.rt_get_wave_times.argtypes = [vp, C.c_int32]
+    d.rt_math_contract.restype = C.c_int
     d.rt_last_kernel_ms.restype = C.c_float
     d.rt_kernel_timing_reset.restype = None
     d.rt_kernel_timing_mean_ms.argtypes = [P(C.c_int32)]
     d.rt_kernel_timing_mean_ms.restype = C.c_float
-    d.rt_test_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
-    d.rt_test_rcp_sweep.argtypes = [vp]
-    d.rt_test_srgb_sweep.argtypes = [vp]
-    d.rt_test_quantize_sweep.argtypes = [vp]
-    d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
-    d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
-    d.rt_test_trace_stream.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
-    d.rt_test_tile_order.argtypes = [C.c_int32, vp, vp]
     d.rt_set_devices.argtypes = [C.c_int32, C.c_int32]
     d.rt_device_count.restype = C.c_int32
-    d.rt_set_pipeline.argtypes = [C.c_int32]
-    d.rt_get_pipeline.restype = C.c_int32
-    d.rt_set_wavefront_capacity.argtypes = [C.c_int64]
-    d.rt_set_wavefront_capacity.restype = None
     d.rt_scene_verify.argtypes = [P(abi.Scene)]
     d.rt_get_frame_timing.argtypes = [P(abi.RT_Frame_Timing)]
     d.render_thread_proc.argtypes = [P(abi.Rendering_Context)]
@@ -149,7 +147,29 @@ def _declare(d):
     d.rt_denoise.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
 
 
-lib = _Lazy()
+def _declare_diag(d):
+    """include/rt_hip_diag.h"""
+    vp = C.c_void_p
+    d.rt_test_math.argtypes = [C.c_int32, C.c_int32, vp, vp, vp]
+    d.rt_test_rcp_sweep.argtypes = [vp]
+    d.rt_test_srgb_sweep.argtypes = [vp]
+    d.rt_test_quantize_sweep.argtypes = [vp]
+    d.rt_test_trace.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    d.rt_test_texture.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    d.rt_test_trace_stream.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    d.rt_test_tile_order.argtypes = [C.c_int32, vp, vp]
+    d.rt_set_pipeline.argtypes = [C.c_int32]
+    d.rt_get_pipeline.restype = C.c_int32
+    d.rt_set_wavefront_capacity.argtypes = [C.c_int64]
+    d.rt_set_wavefront_capacity.restype = None
+    d.rt_get_sched_stats.argtypes = [vp]
+    d.rt_get_wave_times.argtypes = [vp, C.c_int32]
+    d.rt_diag_set_tokens.argtypes = [vp, vp, vp]
+    d.rt_diag_set_tokens.restype = None
+
+
+lib = _Lazy(LIB_PATH)
+diag = _Lazy(DIAG_PATH, diag=True)
 
 
 def symbol_address(name):
@@ -157,5 +177,5 @@ def symbol_address(name):
     return C.cast(getattr(lib, name), C.c_void_p).value
 
 
-def last_error():
-    return (lib.rt_last_error() or b"").decode("utf-8", "replace")
+def last_error(which=None):
+    return ((which or lib).rt_last_error() or b"").decode("utf-8", "replace")

@@ -6,7 +6,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import ctypes_abi as abi
-from .native import lib, last_error
+from .native import lib as _lib, last_error
 from .scene import HostScene, make_image
 
 
@@ -33,16 +33,19 @@ class Counters:
                 + 48.0 * self.textured + 12.0 * self.backgrounds) / self.rays
 
 
-def get_counters() -> Counters:
+def get_counters(lib=None) -> Counters:
+    lib = lib or _lib
     c = abi.RT_Counters()
     if lib.rt_get_counters(C.byref(c)) != 0:
-        raise RuntimeError(last_error())
+        raise RuntimeError(last_error(lib))
     return Counters.from_struct(c)
 
 
 def render_frame(hs: HostScene, width, height, samples, max_bounces, seed=0x1234ABCD, want_linear=False,
-                 want_accum=False):
-    """One frame on GPU 0 through rt_render_frame.  Returns dict(image u8 HxWx3, linear, accum, counters)."""
+                 want_accum=False, lib=None):
+    """One frame on GPU 0 through rt_render_frame.  Returns dict(image u8 HxWx3, linear, accum, counters).
+    lib: the library to render with (default: the product; tests pass raytracing_c_amd.diag for the wavefront pipeline)."""
+    lib = lib or _lib
     lib.rt_set_seed(seed)
     out = np.zeros((height, width, 3), np.uint8)
     img, _keep = make_image(out)
@@ -53,13 +56,14 @@ def render_frame(hs: HostScene, width, height, samples, max_bounces, seed=0x1234
                              linear.ctypes.data if want_linear else None,
                              accum.ctypes.data if want_accum else None)
     if rc != 0:
-        raise RuntimeError("rt_render_frame failed: " + last_error())
-    return dict(image=out, linear=linear, accum=accum, counters=get_counters())
+        raise RuntimeError("rt_render_frame failed: " + last_error(lib))
+    return dict(image=out, linear=linear, accum=accum, counters=get_counters(lib))
 
 
 def render_context(hs: HostScene, width, height, samples, max_bounces, n_threads=1, seed=0x1234ABCD):
     """The reference driver's protocol (driver.c:793-818): n_threads threads enter
     render_thread_proc on one Rendering_Context, the caller polls is_finished."""
+    lib = _lib
     lib.rt_set_seed(seed)
     out = np.zeros((height, width, 3), np.uint8)
     ctx = abi.Rendering_Context()

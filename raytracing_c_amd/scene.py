@@ -117,6 +117,9 @@ class HostScene:
         if not self._freed:
             try:
                 lib.rt_scene_invalidate(C.byref(self.scene))
+                from . import native
+                if native.diag._dll is not None:            # a test process that rendered this scene through the diagnostic library too
+                    native.diag.rt_scene_invalidate(C.byref(self.scene))
             except Exception:
                 pass
             lib.rt_scene_free(C.byref(self.scene))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Worker of tests/test_gpu_diag.py: runs in its OWN process with RT_LIB_PATH = librt_hip_diag.so (the build that carries the
+"""Worker of tests/test_gpu_diag.py and tests/test_gpu_contract_v1.py: runs in its OWN process with RT_LIB_PATH = librt_hip_diag.so
+(or librt_hip_v1.so, the product under numeric contract v1) -- the diagnostic build carries the
 superseded kernel generations and reads the RT_* experiment knobs from the environment at every launch) and renders a
 list of jobs.  stdin: JSON list of {config, w, h, s, b, env: {...}, slabs: [...]}; stdout: one JSON line per job with the
 sha256 of the radiance sums per slab and the counters of the last launch."""
@@ -20,13 +21,13 @@ def main():
     import raytracing_c_amd as rt
     from raytracing_c_amd import ctypes_abi as abi
     from raytracing_c_amd.configs import load_config
-    assert rt.native.LIB_PATH.endswith("librt_hip_diag.so"), rt.native.LIB_PATH
+    assert os.path.basename(rt.native.LIB_PATH) in ("librt_hip_diag.so", "librt_hip_v1.so"), rt.native.LIB_PATH
     assert rt.lib.rt_init(0) == 0, rt.last_error()
     scenes = {}
     for job in jobs:
-        name = job["config"]
+        name = job["config"] + ":" + job.get("shader", "disney")
         if name not in scenes:
-            hs, _ = load_config(name)
+            hs, _ = load_config(job["config"], shader=job.get("shader", "disney"))
             d = rt.lib.rt_scene_upload(C.byref(hs.scene))
             assert d, rt.last_error()
             scenes[name] = (hs, d)
@@ -38,13 +39,14 @@ def main():
             w, h, s, b = job["w"], job["h"], job["s"], job["b"]
             for slab in job.get("slabs", [0]):
                 accum = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda")
-                p = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, 0, 1, slab, 0)
+                p = abi.RT_Render_Params(w, h, s, b, job.get("seed", 0x1234ABCD), 0, 1, slab, 0)
                 if rt.lib.rt_render_accumulate(d, C.byref(p), accum.data_ptr(), None) != 0:
                     raise RuntimeError(rt.last_error())
                 torch.cuda.synchronize()
                 out["digests"].append(hashlib.sha256(accum.cpu().numpy().tobytes()).hexdigest())
             c = rt.render.get_counters()
             out["counters"] = [c.rays, c.node_visits, c.leaf_visits, c.shades]
+            out["contract"] = int(rt.lib.rt_math_contract())
         except Exception as e:           # noqa: BLE001 -- reported to the parent, which fails the test
             out["error"] = repr(e)
         for k, v in saved.items():

@@ -16,3 +16,12 @@ def pytest_configure(config):
 def oracle():
     from tests import _oracle
     return _oracle.load()
+
+
+@pytest.fixture(scope="session")
+def diag():
+    """librt_hip_diag.so beside the product library: unit-test entry points (include/rt_hip_diag.h), the wavefront pipeline.
+    It recognises the product's material tokens (native._Lazy), so scenes built once serve both libraries."""
+    import raytracing_c_amd as rt
+    assert rt.diag.rt_init(0) == 0, rt.last_error(rt.diag)
+    return rt.diag

@@ -15,6 +15,26 @@ def test_library_exports_every_declared_symbol():
         assert getattr(rt.lib, name) is not None, name
 
 
+def test_product_library_has_one_pipeline_and_no_test_entry_points():
+    """librt_hip.so exports no rt_wf_*, no rt_set_pipeline, no rt_test_*; they live in librt_hip_diag.so
+    (include/rt_hip_diag.h), which exports the product's symbols as well."""
+    import subprocess
+    import raytracing_c_amd as rt
+    from raytracing_c_amd import ctypes_abi as abi
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if l.strip()}
+    prod = exported(rt.native.LIB_PATH)
+    bad = sorted(n for n in prod if n.startswith(("rt_wf_", "rt_test_", "rt_launch_test_")) or "wavefront" in n or n in abi.DIAG_ONLY_SYMBOLS)
+    assert bad == [], bad
+    assert not any("rt_wf_" in n or "rt_test_" in n for n in prod)          # (mangled kernel names included)
+    diag = exported(rt.native.DIAG_PATH)
+    for name in abi.EXPORTED_SYMBOLS + abi.DIAG_ONLY_SYMBOLS:
+        assert name in diag, name
+    for name in abi.DIAG_ONLY_SYMBOLS:
+        assert getattr(rt.diag, name) is not None, name
+
+
 def test_headers_and_symbol_list_agree():
     """Every `extern` function of include/*.h is in EXPORTED_SYMBOLS and vice versa."""
     from raytracing_c_amd import ctypes_abi as abi
@@ -25,6 +45,9 @@ def test_headers_and_symbol_list_agree():
         for m in re.finditer(r"extern\s+[^;(]*?\b(\w+)\s*\(", text):
             declared.add(m.group(1))
     assert declared == set(abi.EXPORTED_SYMBOLS), declared ^ set(abi.EXPORTED_SYMBOLS)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt_hip_diag.h")).read(), flags=re.S)
+    diag_declared = {m.group(1) for m in re.finditer(r"extern\s+[^;(]*?\b(\w+)\s*\(", text)}
+    assert diag_declared == set(abi.DIAG_ONLY_SYMBOLS), diag_declared ^ set(abi.DIAG_ONLY_SYMBOLS)
 
 
 def test_struct_sizes_match_reference_contract():

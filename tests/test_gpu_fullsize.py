@@ -101,7 +101,7 @@ def test_config3_entire_frame_matches_oracle(rt, helmet):
     c = got["counters"]
     for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
         assert want["counters"][k] == getattr(c, k), k
-    assert c.paths == w * h * s == 530841600 and c.rays == 642492860
+    assert c.paths == w * h * s == 530841600 and c.rays == 642493048      # (contract v1: 642492860)
 
 
 def test_config3_additivity_partition_and_determinism(rt, helmet):

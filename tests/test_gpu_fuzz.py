@@ -43,18 +43,19 @@ def test_fuzz_parity(oracle, block):
     import raytracing_c_amd as rt
     from tests import _oracle
     assert rt.lib.rt_init(0) == 0, rt.last_error()
+    assert rt.diag.rt_init(0) == 0, rt.last_error(rt.diag)
+    assert rt.diag.rt_set_pipeline(1) == 0      # every fourth case: the wavefront pipeline of the diagnostic library
     bad = []
     try:
         for seed in range(7000 + 25 * block, 7000 + 25 * (block + 1)):
             hs, w, h, s, b, what = _case(seed)
             want = _oracle.render(hs, w, h, s, b, seed=seed)
-            rt.lib.rt_set_pipeline(1 if seed % 4 == 3 else 0)
-            got = rt.render_frame(hs, w, h, s, b, seed=seed, want_accum=True)
+            got = rt.render_frame(hs, w, h, s, b, seed=seed, want_accum=True, lib=rt.diag if seed % 4 == 3 else None)
             ok = np.array_equal(want["accum"], got["accum"])
             for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
                 ok = ok and want["counters"][k] == getattr(got["counters"], k)
             if not ok:
                 bad.append((seed, what, w, h, s, b))
     finally:
-        rt.lib.rt_set_pipeline(0)
+        rt.diag.rt_set_pipeline(0)
     assert not bad, bad

@@ -115,7 +115,7 @@ def test_frame_timing_is_reported(rt):
 
 
 @pytest.mark.parametrize("n_tiles", [1, 63, 64, 1000, 16384, 32400, 130560])
-def test_preparation_kernel_orders_tiles_by_cost(rt, n_tiles):
+def test_preparation_kernel_orders_tiles_by_cost(rt, n_tiles, diag):
     """One launch replaces round 2's three memsets and five small kernels per frame; its counting sort (per-wave counts,
     no contended atomic) must hand out every tile exactly once, most expensive cost bucket first."""
     rng = np.random.default_rng(n_tiles)
@@ -123,7 +123,7 @@ def test_preparation_kernel_orders_tiles_by_cost(rt, n_tiles):
     cost[rng.random(n_tiles) < 0.3] = 0
     cost[: n_tiles // 3] = 4096                                  # a big bucket, as the sky tiles of a frame are
     order = np.zeros(n_tiles, np.uint32)
-    assert rt.lib.rt_test_tile_order(n_tiles, cost.ctypes.data, order.ctypes.data) == 0, rt.last_error()
+    assert rt.diag.rt_test_tile_order(n_tiles, cost.ctypes.data, order.ctypes.data) == 0, rt.last_error(rt.diag)
     assert np.array_equal(np.sort(order), np.arange(n_tiles, dtype=np.uint32))
 
     def bucket(c):

@@ -45,7 +45,7 @@ MATH_CASES = [
 
 
 @pytest.mark.parametrize("op,name,gx,gy", MATH_CASES, ids=[c[1] for c in MATH_CASES])
-def test_math_bit_exact(rt, oracle, op, name, gx, gy):
+def test_math_bit_exact(rt, oracle, op, name, gx, gy, diag):
     from tests import _oracle
     rng = np.random.default_rng(100 + op)
     x = gx(rng).astype(np.float32)
@@ -55,20 +55,20 @@ def test_math_bit_exact(rt, oracle, op, name, gx, gy):
         y[:8] = [0, 1, -1, 0, 0, 0, 0, 0.25]
     want = _oracle.math(op, x, y)
     got = np.zeros_like(x)
-    rc = rt.lib.rt_test_math(op, x.size, x.ctypes.data, y.ctypes.data if y is not None else None, got.ctypes.data)
+    rc = rt.diag.rt_test_math(op, x.size, x.ctypes.data, y.ctypes.data if y is not None else None, got.ctypes.data)
     assert rc == 0, rt.last_error()
     bad = np.nonzero(_bits(want) != _bits(got))[0]
     assert bad.size == 0, f"{name}: {bad.size} mismatches, first x={x[bad[0]]!r} want={want[bad[0]]!r} got={got[bad[0]]!r}"
 
 
-def test_short_reciprocal_equals_the_division(rt, oracle):
+def test_short_reciprocal_equals_the_division(rt, oracle, diag):
     """Leaf blocks of the tile-stream kernel take 1 / det from rcp_exact() (v_rcp_f32 + one Newton step, scaled by 2^24
     on the way in and out) instead of hipcc's IEEE division sequence.  The claim is equality, not accuracy: every bit
     pattern with |x| < 2^102, both infinities and every NaN is compared on the device with 1.0f / x, and a sample --
     denormals, zeros, infinities, powers of two, all-ones mantissas -- with the CPU's division (the oracle's)."""
     from tests import _oracle
     out = (C.c_uint64 * 4)()
-    assert rt.lib.rt_test_rcp_sweep(out) == 0, rt.last_error()
+    assert rt.diag.rt_test_rcp_sweep(out) == 0, rt.last_error(rt.diag)
     inside_bad, outside_n, outside_bad, first = (int(v) for v in out)
     assert inside_bad == 0, f"first differing pattern {first - 1:#010x}"
     assert outside_n == 2 * 26 * (1 << 23)           # 2^102 <= |x| < infinity: exponent fields 229..254, both signs
@@ -83,28 +83,28 @@ def test_short_reciprocal_equals_the_division(rt, oracle):
     inside = ~((np.abs(x) >= np.float32(2.0 ** 102)) & np.isfinite(x))
     want = _oracle.math(10, x, None)
     got = np.zeros_like(x)
-    assert rt.lib.rt_test_math(11, x.size, x.ctypes.data, None, got.ctypes.data) == 0, rt.last_error()
+    assert rt.diag.rt_test_math(11, x.size, x.ctypes.data, None, got.ctypes.data) == 0, rt.last_error(rt.diag)
     same = (_bits(want) == _bits(got)) | (np.isnan(want) & np.isnan(got))
     assert same[inside].all(), f"x = {x[inside][~same[inside]][:4]!r}"
     assert inside.sum() > 300000 and (~inside).sum() > 1000
 
 
-def test_shift_quantisation_equals_the_double_one(rt):
+def test_shift_quantisation_equals_the_double_one(rt, diag):
     """The tile-stream kernel turns a sample into 32.32 fixed point by shifting the float's mantissa instead of going through
     double (rt_accum_quantize, rt_math.h): the same integer for every one of the 2^32 bit patterns, NaN and negatives (0),
     infinity and anything above 2^20 (clamped) included."""
     out = (C.c_uint64 * 2)()
-    assert rt.lib.rt_test_quantize_sweep(out) == 0, rt.last_error()
+    assert rt.diag.rt_test_quantize_sweep(out) == 0, rt.last_error(rt.diag)
     assert int(out[0]) == 0, f"first differing pattern {int(out[1]) - 1:#010x}"
 
 
-def test_texture_srgb_decode_equals_the_division(rt, oracle):
+def test_texture_srgb_decode_equals_the_division(rt, oracle, diag):
     """The kernels decode a texture sample with (x + 0.055f) * RN(1 / 1.055f) corrected by the exact residual instead of the
     division by 1.055f of common.h:84-91.  Every float in [0, 2] and in [-0.046875, -0.03125] -- a sample lies in [0, 0.9961] --
     gives the same bits as rt_srgb_to_linear1() on the device; a sample of them is compared with the CPU's."""
     from tests import _oracle
     out = (C.c_uint64 * 3)()
-    assert rt.lib.rt_test_srgb_sweep(out) == 0, rt.last_error()
+    assert rt.diag.rt_test_srgb_sweep(out) == 0, rt.last_error(rt.diag)
     n, bad, first = (int(v) for v in out)
     assert n == (1 << 30) + (1 << 22)
     assert bad == 0, f"first differing pattern {first - 1:#010x}"
@@ -112,7 +112,7 @@ def test_texture_srgb_decode_equals_the_division(rt, oracle):
     x = np.concatenate([rng.uniform(0, 1, 200000), rng.uniform(0, 1e-6, 1000), [0.0, 1.0, 0.9961, np.nan]]).astype(np.float32)
     want = _oracle.math(7, x, None)
     got = np.zeros_like(x)
-    assert rt.lib.rt_test_math(13, x.size, x.ctypes.data, None, got.ctypes.data) == 0, rt.last_error()
+    assert rt.diag.rt_test_math(13, x.size, x.ctypes.data, None, got.ctypes.data) == 0, rt.last_error(rt.diag)
     assert np.array_equal(_bits(want)[:-1], _bits(got)[:-1]) and np.isnan(got[-1]) == np.isnan(want[-1])
 
 
@@ -141,7 +141,7 @@ def _rays_for(hs, n, rng):
 
 
 @pytest.mark.parametrize("asset", ["quad.obj", "fov_test.obj", "sheen.glb", "spheres.glb", "tower.obj", "helmet.glb"])
-def test_trace_bit_exact(rt, oracle, asset):
+def test_trace_bit_exact(rt, oracle, asset, diag):
     from raytracing_c_amd.loaders import load_model
     hs = load_model(os.path.join(ASSETS, asset))
     rng = np.random.default_rng(7)
@@ -149,21 +149,21 @@ def test_trace_bit_exact(rt, oracle, asset):
     rays = _rays_for(hs, n, rng)
     wt, wtri, wuv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
     oracle.oracle_trace_rays(C.byref(hs.scene), n, rays.ctypes.data, wt.ctypes.data, wtri.ctypes.data, wuv.ctypes.data)
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
         gt, gtri, guv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
-        rc = rt.lib.rt_test_trace(d, n, rays.ctypes.data, gt.ctypes.data, gtri.ctypes.data, guv.ctypes.data)
+        rc = rt.diag.rt_test_trace(d, n, rays.ctypes.data, gt.ctypes.data, gtri.ctypes.data, guv.ctypes.data)
         assert rc == 0, rt.last_error()
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
     assert (wtri >= 0).sum() > n // 10, "test rays must actually hit the scene"
     assert np.array_equal(wtri, gtri)
     assert np.array_equal(_bits(wt), _bits(gt))
     assert np.array_equal(_bits(wuv), _bits(guv))
 
 
-def test_leaf_known_answers_on_gpu(rt):
+def test_leaf_known_answers_on_gpu(rt, diag):
     """The hand-derived cases of tests/test_oracle_kat.py::test_ray_triangles_hit_8_cases on the device:
     closest of several, equal t -> LOWEST slot wins (min_f32x8, raytracer.c:27-29), t < eps and epsilon-padded
     barycentric bounds (raytracer.c:137-149).  A <= 8 triangle scene is a depth-0 BVH: one leaf group, input order."""
@@ -182,26 +182,26 @@ def test_leaf_known_answers_on_gpu(rt):
                      [-2e-4, 0.25, 0, 0, 0, 1],         # u = -2e-4: outside
                      [0.25, 0.25, 3.5, 0, 0, 1]], np.float32)   # starts between z=3 and z=4 -> slot 5 (z=4), t = 0.5
     n = len(rays)
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
         t, tri_i, uv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
-        assert rt.lib.rt_test_trace(d, n, rays.ctypes.data, t.ctypes.data, tri_i.ctypes.data, uv.ctypes.data) == 0
+        assert rt.diag.rt_test_trace(d, n, rays.ctypes.data, t.ctypes.data, tri_i.ctypes.data, uv.ctypes.data) == 0
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
     assert tri_i.tolist() == [1, -1, 1, -1, 5]
     assert t[0] == 3.0 and np.isinf(t[1]) and t[2] == 3.0 and np.isinf(t[3]) and t[4] == 0.5
     assert uv[0].tolist() == [0.25, 0.25]
 
 
-def test_texture_bit_exact(rt, oracle):
+def test_texture_bit_exact(rt, oracle, diag):
     from raytracing_c_amd.loaders import load_model
     hs = load_model(os.path.join(ASSETS, "helmet.glb"))
     rng = np.random.default_rng(3)
     n = 20000
     uv = rng.uniform(-3, 3, (n, 2)).astype(np.float32)
     uv[:6] = [[0, 0], [1, 1], [-1, -1], [0.99999994, 0.5], [-1e-9, 0.25], [2.5, -0.5]]
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
         cands = [hs.background_image] + list(hs.images)
@@ -214,7 +214,7 @@ def test_texture_bit_exact(rt, oracle):
         seen = set()
         for tex in [-1] + list(range(len(hs.images) + 1)):
             got = np.zeros((n, 3), np.float32)
-            rc = rt.lib.rt_test_texture(d, tex, n, uv.ctypes.data, got.ctypes.data)
+            rc = rt.diag.rt_test_texture(d, tex, n, uv.ctypes.data, got.ctypes.data)
             assert rc == 0, rt.last_error()
             # textures are uploaded in first-use order: identify the host image by content
             match = [k for k, w in enumerate(wants) if np.array_equal(_bits(w), _bits(got))]
@@ -222,7 +222,7 @@ def test_texture_bit_exact(rt, oracle):
             seen.add(match[0])
         assert seen == set(range(len(cands)))
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
 
 
 # ---------------------------------------------------------------------------------------

@@ -73,7 +73,7 @@ def test_random_scene_bit_exact(oracle, seed, n_tris):
         assert c.shades > 200 and c.textured > 50, "the scene must exercise shading and textures"
 
 
-def test_duplicate_triangles_resolve_ties_like_the_oracle(oracle):
+def test_duplicate_triangles_resolve_ties_like_the_oracle(oracle, diag):
     """Two coincident triangles with different materials: the hit must go to the one the reference's
     traversal order finds first (strict <), so the image differs if the two are swapped."""
     import ctypes as C
@@ -87,13 +87,13 @@ def test_duplicate_triangles_resolve_ties_like_the_oracle(oracle):
     rays = _rays_for(hs, n, rng)
     wt, wtri, wuv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
     oracle.oracle_trace_rays(C.byref(hs.scene), n, rays.ctypes.data, wt.ctypes.data, wtri.ctypes.data, wuv.ctypes.data)
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
         gt, gtri, guv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
-        assert rt.lib.rt_test_trace(d, n, rays.ctypes.data, gt.ctypes.data, gtri.ctypes.data, guv.ctypes.data) == 0
+        assert rt.diag.rt_test_trace(d, n, rays.ctypes.data, gt.ctypes.data, gtri.ctypes.data, guv.ctypes.data) == 0
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
     assert np.array_equal(wtri, gtri) and np.array_equal(wt.view(np.uint32), gt.view(np.uint32))
     # ties really occur: some hit triangle has an exact duplicate elsewhere in the triangle block
     soa = hs.soa_array().T                           # (slots, 9)

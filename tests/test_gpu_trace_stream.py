@@ -89,9 +89,9 @@ def _gpu_trace(rt, d, rays, pyramid=None, exit_lanes=48, mode=0):
     t, tri, uv = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
     visits = (C.c_uint64 * 2)()
     pyr = None if pyramid is None else np.ascontiguousarray(pyramid, np.float32)
-    rc = rt.lib.rt_test_trace_stream(d, n, rays.ctypes.data, None if pyr is None else pyr.ctypes.data, exit_lanes, mode,
+    rc = rt.diag.rt_test_trace_stream(d, n, rays.ctypes.data, None if pyr is None else pyr.ctypes.data, exit_lanes, mode,
                                      t.ctypes.data, tri.ctypes.data, uv.ctypes.data, visits)
-    assert rc == 0, rt.last_error()
+    assert rc == 0, rt.last_error(rt.diag)
     return t, tri, uv, (int(visits[0]), int(visits[1]))
 
 
@@ -105,45 +105,45 @@ def _same(want, got):
 
 
 @pytest.mark.parametrize("asset", ["quad.obj", "fov_test.obj", "sheen.glb", "spheres.glb", "tower.obj", "helmet.glb"])
-def test_production_traversal_is_bit_exact(rt, oracle, asset):
+def test_production_traversal_is_bit_exact(rt, oracle, asset, diag):
     from raytracing_c_amd.loaders import load_model
     hs = load_model(os.path.join(ASSETS, asset))
     rng = np.random.default_rng(11)
     rays = _rays(hs, 30000, rng)
     want = _oracle_trace(oracle, hs, rays)
     assert (want[1] >= 0).sum() > len(rays) // 10, "test rays must actually hit the scene"
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
         for mode in (0, 1, 2):                      # short reciprocal + LDS nodes | IEEE division | nodes through L1 / L2
             for exit_lanes in (48, 1, 64):
                 _same(want, _gpu_trace(rt, d, rays, None, exit_lanes, mode))
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
 
 
-def test_sah_scene_and_inverted_boxes(rt, oracle):
+def test_sah_scene_and_inverted_boxes(rt, oracle, diag):
     """The opt-in SAH builder's tree, and a tree whose boxes are not min <= max (the LDS node blocks must not be used)."""
     from raytracing_c_amd.configs import load_config
     from tests.test_gpu_random_scenes import make_scene
     rng = np.random.default_rng(5)
     hs, _ = load_config("helmet", builder="sah")
     rays = _rays(hs, 20000, rng)
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     try:
         _same(_oracle_trace(oracle, hs, rays), _gpu_trace(rt, d, rays))
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
     hs = make_scene(3, 700)
     nodes = np.ctypeslib.as_array(C.cast(hs.scene.bvh.nodes.data, C.POINTER(C.c_float)), (int(hs.scene.bvh.nodes.len) * 48,))
     nb = nodes.reshape(-1, 2, 24)
     nb[1::3] = nb[1::3, ::-1].copy()               # swap mins and maxs of every third node: inverted boxes
     rays = _rays(hs, 20000, rng)
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     try:
         _same(_oracle_trace(oracle, hs, rays), _gpu_trace(rt, d, rays))
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)
 
 
 def _pyramid(origin, dirs, margin=0.02):
@@ -175,7 +175,7 @@ def _pyramid(origin, dirs, margin=0.02):
 
 
 @pytest.mark.parametrize("asset", ["helmet.glb", "spheres.glb", "tower.obj"])
-def test_pyramid_culled_node_blocks(rt, oracle, asset):
+def test_pyramid_culled_node_blocks(rt, oracle, asset, diag):
     """Bundles of rays from one origin inside a narrow pyramid -- what the camera rays of an 8x8 tile are -- take the culled
     node block (pyramid_cull_mask + node_enter_few, 1 to 4 surviving children) and must still visit exactly the oracle's nodes and
     leaves.  Bundles of several widths from far, near and inside the model, so that every survivor count occurs."""
@@ -184,7 +184,7 @@ def test_pyramid_culled_node_blocks(rt, oracle, asset):
     lo, hi = _bbox(hs)
     c, e = (lo + hi) / 2, np.maximum(hi - lo, 1e-3)
     rng = np.random.default_rng(23)
-    d = rt.lib.rt_scene_upload(C.byref(hs.scene))
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     try:
         hits = 0
@@ -206,4 +206,4 @@ def test_pyramid_culled_node_blocks(rt, oracle, asset):
             _same(want, _gpu_trace(rt, d, rays, pyr, 1, 1))
         assert hits > 10000
     finally:
-        rt.lib.rt_scene_release(d)
+        rt.diag.rt_scene_release(d)

@@ -1,5 +1,5 @@
 """The wavefront pipeline (csrc/rt_wavefront.hip: camera / shade / trace kernels joined by record queues in HBM), selected
-with rt_set_pipeline(1): same radiance sums and the same seven counters as the oracle, bit for bit -- also when the hit queue is
+with rt_set_pipeline(1) of the DIAGNOSTIC library (the product library has one pipeline): same radiance sums and the same seven counters as the oracle, bit for bit -- also when the hit queue is
 so small that a frame takes many passes, and with bounce limits beyond what any path reaches."""
 import numpy as np
 import pytest
@@ -11,10 +11,11 @@ pytestmark = pytest.mark.gpu
 def rt():
     import raytracing_c_amd as rt
     assert rt.lib.rt_init(0) == 0, rt.last_error()
-    assert rt.lib.rt_set_pipeline(1) == 0
+    assert rt.diag.rt_init(0) == 0, rt.last_error(rt.diag)
+    assert rt.diag.rt_set_pipeline(1) == 0
     yield rt
-    rt.lib.rt_set_pipeline(0)
-    rt.lib.rt_set_wavefront_capacity(96 << 20)
+    rt.diag.rt_set_pipeline(0)
+    rt.diag.rt_set_wavefront_capacity(96 << 20)
 
 
 def _check(rt, name, w, h, s, b, **kw):
@@ -22,7 +23,7 @@ def _check(rt, name, w, h, s, b, **kw):
     from tests import _oracle
     hs, _ = load_config(name, **kw)
     want = _oracle.render(hs, w, h, s, b)
-    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True, lib=rt.diag)
     assert np.array_equal(got["accum"], want["accum"])
     assert np.array_equal(got["image"], want["image"])
     c = got["counters"]
@@ -38,6 +39,6 @@ def test_wavefront_frames_are_bit_exact(rt, oracle, name, w, h, s, b):
 
 
 def test_many_passes_through_a_tiny_queue(rt, oracle):
-    rt.lib.rt_set_wavefront_capacity(1024)          # the camera kernel fills its hit queue again and again
+    rt.diag.rt_set_wavefront_capacity(1024)         # the camera kernel fills its hit queue again and again
     _check(rt, "helmet", 192, 108, 8, 8)
     _check(rt, "spheres", 128, 128, 16, 4, builder="sah")

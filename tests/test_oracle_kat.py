@@ -19,6 +19,29 @@ ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 F = np.float32
 
 
+def fma32(a, b, c):
+    """fmaf(a, b, c): a * b + c with ONE rounding to float32 (numeric contract v2, include/rt_math.h), exactly: the
+    product and the sum in rational arithmetic, then round to nearest even."""
+    from fractions import Fraction
+    a, b, c = F(a), F(b), F(c)
+    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+        with np.errstate(invalid="ignore", over="ignore"):
+            return F(np.float64(a) * np.float64(b) + np.float64(c))      # inf / NaN propagate like the hardware's
+    exact = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    if exact == 0:
+        return F(float(a) * float(b) + float(c))                          # (sign of zero as IEEE: exact sum of the two)
+    g = F(float(exact))                                                    # double rounding can be off by one ulp: fix up
+    best = None
+    for cand in (np.nextafter(g, F(-np.inf)), g, np.nextafter(g, F(np.inf))):
+        if not np.isfinite(cand):
+            continue
+        err = abs(Fraction(float(cand)) - exact)
+        even = (int(np.array(cand, F).view(np.uint32)) & 1) == 0
+        if best is None or err < best[0] or (err == best[0] and even and not best[2]):
+            best = (err, cand, even)
+    return F(best[1])
+
+
 # --- common.h:13-24 -----------------------------------------------------------------------
 
 def py_rand_u32(state):
@@ -109,10 +132,17 @@ def test_srgb_curves(oracle):
 # --- raytracer.c:190-230 ------------------------------------------------------------------
 
 def np_slab(o, d, mn, mx, t_min, t_max):
-    with np.errstate(divide="ignore", invalid="ignore"):
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         inv = F(1.0) / d
-        t0 = (mn - o) * inv
-        t1 = (mx - o) * inv
+        bias = -(o * inv)
+        if np.all(np.isfinite(inv)) and np.all(np.isfinite(bias)):
+            # contract v2, NaN-free ray: every plane distance is ONE fused multiply-add (rt_slab_t_fast)
+            t0 = np.array([fma32(mn[i], inv[i], bias[i]) for i in range(3)], F)
+            t1 = np.array([fma32(mx[i], inv[i], bias[i]) for i in range(3)], F)
+        else:
+            # the reference's own form (raytracer.c:203-208), also what contract v1 computes for every ray
+            t0 = (mn - o) * inv
+            t1 = (mx - o) * inv
 
     def mn2(a, b):
         return a if a < b else b
@@ -136,7 +166,9 @@ def test_ray_aabbs_hit_8_cases(oracle):
         node.min_x[k], node.min_y[k], node.min_z[k] = mn
         node.max_x[k], node.max_y[k], node.max_z[k] = mx
     rays = [((0, 0, -5), (0, 0, 1)), ((-5, 0, 0), (1, 0, 0)), ((0, 0, 0), (0, 1, 0)),
-            ((0.25, 0.3, -5), (0.1, 0.05, 0.99)), ((0, 0, 0), (0.57735026, 0.57735026, 0.57735026))]
+            ((0.25, 0.3, -5), (0.1, 0.05, 0.99)), ((0, 0, 0), (0.57735026, 0.57735026, 0.57735026)),
+            ((0.37, -0.21, -4.9), (0.123, 0.077, 0.989)), ((7.3, 3.1, -2.2), (-0.81, -0.33, 0.48)),
+            ((1e30, 0, 0), (-1e-9, 0.3, 0.95))]          # bias overflows: this ray keeps the unfused form
     for (o, d) in rays:
         for t_max in (np.inf, 4.5):
             ray = abi.Ray(abi.Vec3(*o), abi.Vec3(*d))
@@ -236,8 +268,8 @@ def np_bilinear(pix, tx, ty):
     def tex(uu, vv):
         return (pix[vv, uu, :3].astype(F) / F(255.999)).astype(F)
 
-    def lerp(p, q, t):
-        return (p * F(F(1.0) - t) + q * t).astype(F)
+    def lerp(p, q, t):              # rt_lerpf: fma(q, t, p * (1 - t))
+        return np.array([fma32(q[i], t, F(p[i] * F(F(1.0) - t))) for i in range(3)], F)
     c0 = lerp(tex(u, v), tex(u2, v), a)
     c1 = lerp(tex(u, v2), tex(u2, v2), a)
     return lerp(c0, c1, b)

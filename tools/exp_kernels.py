@@ -46,7 +46,8 @@ def main():
             saved = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             # (the product library reads no experiment knob from the environment: the pipeline is chosen through the API)
-            rt.lib.rt_set_pipeline(1 if os.environ.get("RT_PIPELINE") == "wf" else 0)
+            if hasattr(rt.lib, "rt_set_pipeline"):           # diagnostic library only (RT_LIB_PATH=.../librt_hip_diag.so)
+                rt.lib.rt_set_pipeline(1 if os.environ.get("RT_PIPELINE") == "wf" else 0)
             full = run(0, 1, reps)
             digest = hashlib.sha256(accum.cpu().numpy().tobytes()).hexdigest()[:12]
             c = rt.render.get_counters()
