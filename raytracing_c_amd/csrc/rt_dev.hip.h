@@ -48,8 +48,21 @@ struct Ray3 {
 
 // The slab biases -(o * inv) of numeric contract v2 (rt_math.h): recomputed where a block needs them (three
 // multiplications per block) instead of kept in three more registers per lane across the whole loop.
+// (The products are loop invariants of the traversal loop: left to the compiler they are hoisted out of it and kept -- the
+// three registers this function exists to save, 47 more spilled VGPRs when it was tried.  A volatile asm stays where it is;
+// v_mul_f32 is the instruction the compiler emits for o * inv, the negation rides on the fma's source modifier.)
 __device__ __forceinline__ rt_v3 slab_bias3(const Ray3 &r) {
+#ifdef RT_MATH_NO_FMA
+  return rt_v3_make(0.0f, 0.0f, 0.0f);           // contract v1: rt_slab_t_fast() does not read it
+#elif defined(RT_BIAS_PLAIN)
   return rt_v3_make(rt_slab_bias(r.o.x, r.inv_x), rt_slab_bias(r.o.y, r.inv_y), rt_slab_bias(r.o.z, r.inv_z));
+#else
+  float px, py, pz;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(px) : "v"(r.o.x), "v"(r.inv_x));
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(py) : "v"(r.o.y), "v"(r.inv_y));
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(pz) : "v"(r.o.z), "v"(r.inv_z));
+  return rt_v3_make(-px, -py, -pz);
+#endif
 }
 
 struct HitRec {
@@ -105,19 +118,11 @@ __device__ __forceinline__ float slab_entry(const Ray3 &r, const rt_v3 &bs, floa
     // t_maxv <= t_max, so "entry < exit" already implies the candidate test entry < t_max
     return (t_minv < t_maxv) ? t_minv : RT_INF;
   } else {
-    // a block that holds ONE ray that is not NaN-free runs this instantiation for all its lanes: every lane takes the
-    // plane distances in the form ITS ray is entitled to (they round differently under contract v2); min / max in the
-    // reference's operand order are plain min / max on the NaN-free ones
-    float t0x, t1x, t0y, t1y, t0z, t1z;
-    if (r.fast) {
-      t0x = rt_slab_t_fast(mnx, r.o.x, r.inv_x, bs.x); t1x = rt_slab_t_fast(mxx, r.o.x, r.inv_x, bs.x);
-      t0y = rt_slab_t_fast(mny, r.o.y, r.inv_y, bs.y); t1y = rt_slab_t_fast(mxy, r.o.y, r.inv_y, bs.y);
-      t0z = rt_slab_t_fast(mnz, r.o.z, r.inv_z, bs.z); t1z = rt_slab_t_fast(mxz, r.o.z, r.inv_z, bs.z);
-    } else {
-      t0x = rt_slab_t_exact(mnx, r.o.x, r.inv_x); t1x = rt_slab_t_exact(mxx, r.o.x, r.inv_x);
-      t0y = rt_slab_t_exact(mny, r.o.y, r.inv_y); t1y = rt_slab_t_exact(mxy, r.o.y, r.inv_y);
-      t0z = rt_slab_t_exact(mnz, r.o.z, r.inv_z); t1z = rt_slab_t_exact(mxz, r.o.z, r.inv_z);
-    }
+    // ONLY for rays that are not NaN-free (Ray3::fast false): under contract v2 the two forms round differently, so a
+    // NaN-free ray must never come through here (callers branch per lane: traversal_blocks, trace_ray)
+    float t0x = rt_slab_t_exact(mnx, r.o.x, r.inv_x), t1x = rt_slab_t_exact(mxx, r.o.x, r.inv_x);
+    float t0y = rt_slab_t_exact(mny, r.o.y, r.inv_y), t1y = rt_slab_t_exact(mxy, r.o.y, r.inv_y);
+    float t0z = rt_slab_t_exact(mnz, r.o.z, r.inv_z), t1z = rt_slab_t_exact(mxz, r.o.z, r.inv_z);
     float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
     float bx = rt_max_ps(t0x, t1x), by = rt_max_ps(t0y, t1y), bz = rt_max_ps(t0z, t1z);
     float t_minv = rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
@@ -129,29 +134,29 @@ __device__ __forceinline__ float slab_entry(const Ray3 &r, const rt_v3 &bs, floa
 
 // Entry distance of child j only; the miss test against t_max was already passed
 // when the node was entered, so only t_minv is needed (see header comment).
-// (called per lane: a FAST instantiation must only see rays with Ray3::fast, the other one takes the form the ray's
-// own `fast` flag selects -- the two forms differ in their rounding under contract v2)
+// FAST: only for rays with Ray3::fast; the other instantiation only for rays without (the two forms round differently
+// under contract v2).  slab_entry_child_any() branches per lane.
 template <bool FAST>
 __device__ __forceinline__ float slab_entry_child(const float *n, const Ray3 &r) {
   // n -> element j of the node's first row; the six rows are 8 floats apart
   float mnx = n[0], mny = n[8], mnz = n[16], mxx = n[24], mxy = n[32], mxz = n[40];
-  float t0x, t1x, t0y, t1y, t0z, t1z;
-  if (FAST || r.fast) {
-    const rt_v3 bs = slab_bias3(r);
-    t0x = rt_slab_t_fast(mnx, r.o.x, r.inv_x, bs.x); t1x = rt_slab_t_fast(mxx, r.o.x, r.inv_x, bs.x);
-    t0y = rt_slab_t_fast(mny, r.o.y, r.inv_y, bs.y); t1y = rt_slab_t_fast(mxy, r.o.y, r.inv_y, bs.y);
-    t0z = rt_slab_t_fast(mnz, r.o.z, r.inv_z, bs.z); t1z = rt_slab_t_fast(mxz, r.o.z, r.inv_z, bs.z);
-  } else {
-    t0x = rt_slab_t_exact(mnx, r.o.x, r.inv_x); t1x = rt_slab_t_exact(mxx, r.o.x, r.inv_x);
-    t0y = rt_slab_t_exact(mny, r.o.y, r.inv_y); t1y = rt_slab_t_exact(mxy, r.o.y, r.inv_y);
-    t0z = rt_slab_t_exact(mnz, r.o.z, r.inv_z); t1z = rt_slab_t_exact(mxz, r.o.z, r.inv_z);
-  }
   if (FAST) {
+    const rt_v3 bs = slab_bias3(r);
+    float t0x = rt_slab_t_fast(mnx, r.o.x, r.inv_x, bs.x), t1x = rt_slab_t_fast(mxx, r.o.x, r.inv_x, bs.x);
+    float t0y = rt_slab_t_fast(mny, r.o.y, r.inv_y, bs.y), t1y = rt_slab_t_fast(mxy, r.o.y, r.inv_y, bs.y);
+    float t0z = rt_slab_t_fast(mnz, r.o.z, r.inv_z, bs.z), t1z = rt_slab_t_fast(mxz, r.o.z, r.inv_z, bs.z);
     float sx = fmin_hw(t0x, t1x), sy = fmin_hw(t0y, t1y), sz = fmin_hw(t0z, t1z);
     return fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
   }
+  float t0x = rt_slab_t_exact(mnx, r.o.x, r.inv_x), t1x = rt_slab_t_exact(mxx, r.o.x, r.inv_x);
+  float t0y = rt_slab_t_exact(mny, r.o.y, r.inv_y), t1y = rt_slab_t_exact(mxy, r.o.y, r.inv_y);
+  float t0z = rt_slab_t_exact(mnz, r.o.z, r.inv_z), t1z = rt_slab_t_exact(mxz, r.o.z, r.inv_z);
   float sx = rt_min_ps(t0x, t1x), sy = rt_min_ps(t0y, t1y), sz = rt_min_ps(t0z, t1z);
   return rt_max_ps(RT_EPS, rt_max_ps(sx, rt_max_ps(sy, sz)));
+}
+__device__ __forceinline__ float slab_entry_child_any(const float *n, const Ray3 &r) {
+  if (r.fast) return slab_entry_child<true>(n, r);
+  return slab_entry_child<false>(n, r);
 }
 
 // Tests the 8 children of `node` against the ray with t_max = hit_t and returns
@@ -176,7 +181,7 @@ template <bool FAST, int MODE>
 __device__ __forceinline__ uint32_t node_enter(const RT_KParams &P, const Ray3 &r, int node, float hit_t,
                                                const float4 *lds_nodes) {
   int d[8];
-  const rt_v3 bs = slab_bias3(r);
+  const rt_v3 bs = FAST ? slab_bias3(r) : rt_v3_make(0.0f, 0.0f, 0.0f);
   if (MODE == NODE_SCALAR) {               // `node` is wave-uniform: node data lives in SGPRs
     cfloat *nb = as_scalar_ptr(P.nodes) + (size_t)node * 48;
 #pragma unroll
@@ -1161,6 +1166,10 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
         } else if (all_fast) {
           if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
           else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+        } else if (ray.fast) {
+          // a block that holds a ray that is not NaN-free (axis-aligned, 0 * inf): every lane takes the form ITS ray is
+          // entitled to -- the two round differently under contract v2 -- in two passes over the block's lanes
+          cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
         } else {
           cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
         }
@@ -1212,7 +1221,7 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
               dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
               if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
             } else {
-              dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
+              dj = slab_entry_child_any(P.nodes + (size_t)node * 48 + j, ray);
             }
             if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
           }

@@ -365,6 +365,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             // outside the copy come through L1/L2.  (A scalar-cache path for wave-uniform nodes was measured: slower.)
             if (LDSN && __ballot(node >= n_lds) == 0) { STAT(6, nN); cur = node_enter<true, NODE_LDS>(P, ray, node, hit.t, lds_nodes); }
             else { STAT(5, nN); cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes); }
+          } else if (ray.fast) {       // (mixed block: every lane in the form its own ray is entitled to, see traversal_blocks)
+            cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
           } else {
             cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
           }
@@ -412,8 +414,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             bool go = true;
             if ((dirty >> level) & 1u) {
               float dj;
-              if (LDSN && node < n_lds) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
-              else dj = slab_entry_child<false>(P.nodes + (size_t)node * 48 + j, ray);
+              if (LDSN && node < n_lds) dj = slab_entry_child_any(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
+              else dj = slab_entry_child_any(P.nodes + (size_t)node * 48 + j, ray);
               if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
             }
             if (go) {
