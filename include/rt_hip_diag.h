@@ -31,6 +31,9 @@ extern void rt_set_wavefront_capacity(i64 records);
  * out[16..23] = shader-clock cycles the waves spent in S blocks with shading (16), S blocks without (17), leaf
  * blocks (19), node blocks (21), pop loops (23), summed over waves; out[24] = cycles of the whole wave loops. */
 extern int rt_get_sched_stats(u64 out[32]);
+/* Block ledger of a -DRT_LEDGER build of the tile-stream kernel (tools/exp_ledger.py): out[0 .. n) = the LG_* slots of
+ * csrc/rt_dev.hip.h of the last launch (all zero in other builds). */
+extern int rt_get_ledger(u64 *out, i32 n);
 /* ... and per wave (start tick, end tick, items) of the last diagnostic launch; ticks are 10 ns.  Returns the wave count. */
 extern int rt_get_wave_times(u64 *out, i32 max_waves);
 

@@ -1731,6 +1731,17 @@ extern "C" int rt_get_sched_stats(u64 out[32]) {
   return 0;
 }
 
+// Block ledger of a -DRT_LEDGER build of the tile-stream kernel (LG_* slots, rt_dev.hip.h): out[0 .. n) = counters[8 .. 8 + n).
+extern "C" int rt_get_ledger(u64 *out, i32 n) {
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0 || !out || n < 0 || n > RT_N_COUNTERS - 8) return -1;
+  unsigned long long c[RT_N_COUNTERS];
+  if (read_counters(D, c) != 0) return -1;
+  for (int i = 0; i < n; i++) out[i] = c[8 + i];
+  return 0;
+}
+
 // Diagnostic kernel (RT_KERNEL=4): per wave start time, end time (100 MHz ticks) and items processed.
 extern "C" int rt_get_wave_times(u64 *out, i32 max_waves) {
   Device &D = dev0();

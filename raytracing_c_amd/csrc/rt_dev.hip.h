@@ -75,6 +75,53 @@ struct LaneCounters {
   uint32_t rays, nodes, leaves, shades, bgs, textured, paths;
 };
 
+// ---- block ledger (-DRT_LEDGER builds only; tools/exp_ledger.py, profiles/r04_blocks.md) ----------------------------------------
+// Wave-level counters (scalar registers) of how often every block of the tile-stream kernel runs and with how many lanes, plus
+// comment markers in the ISA (LGM) from which tools/ledger_static.py counts the instructions of each block.  The product
+// build compiles none of this.
+enum {
+  // group 1: the S block
+  LG_S_ITER = 0, LG_ENV_X, LG_ENV_L, LG_SHADE_X, LG_SHADE_L, LG_PSTORE_X, LG_PSTORE_L, LG_PLOAD_X, LG_PLOAD_L, LG_ACCUM_X, LG_ACCUM_L,
+  // group 2: regeneration, ray start, tiles, loop rounds
+  LG_REGEN_X, LG_REGEN_L, LG_START_X, LG_START_L, LG_PRIM_X, LG_PRIM_L, LG_TILE_X, LG_JOIN_X, LG_FLUSH_X, LG_GRAB_X, LG_ROUND_X, LG_TRAV_CALLS,
+  // group 3: full node blocks
+  LG_NFULL_X, LG_NFULL_L, LG_NFULL_CAM, LG_NGLOB_X, LG_NGLOB_L, LG_NEXACT_X, LG_NEXACT_L, LG_CULLMASK_X, LG_PYRCHK_X, LG_NODE_WAIT_L,
+  // group 4: pyramid-culled node blocks by number of surviving children
+  LG_NFEW0_X, LG_NFEW1_X, LG_NFEW2_X, LG_NFEW3_X, LG_NFEW4_X, LG_NFEW0_L, LG_NFEW1_L, LG_NFEW2_L, LG_NFEW3_L, LG_NFEW4_L,
+  // group 5: leaf blocks and pop loops
+  LG_LEAF_X, LG_LEAF_L, LG_LEAF_CAM, LG_POP_X, LG_POP_L, LG_POP_UP_L, LG_POP_RETEST_L, LG_POP_CAM, LG_POP_UP_X, LG_POP_RETEST_X, LG_POP_DONE_L,
+  // group 6: shader-clock cycles (>> 4) per kind of block, summed over waves
+  LG_CYC_S, LG_CYC_NODE, LG_CYC_LEAF, LG_CYC_POP, LG_CYC_WAVE, LG_CYC_TILE,
+  LG_N
+};
+// The counters live in MEMORY, one row of 64 dwords per wave (g_ledger, rt_kernels.hip), bumped by lane 0 with atomics that
+// return nothing: as scalar registers they did not fit beside the kernel's own (59 of them: 286 spilled VGPRs; even a
+// dozen: 50-80), which would have measured a different kernel.  -DRT_LEDGER=1 counts blocks and lanes, =2 adds the
+// shader-clock cycles per kind of block (s_memtime around the blocks: perturbs more).
+#ifdef RT_LEDGER
+__device__ __forceinline__ int lane_now();
+__device__ __forceinline__ void lg_add(uint32_t *lg, int slot, uint32_t n) {
+  if (lane_now() == 0 && n != 0u) __hip_atomic_fetch_add(lg + slot, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define LG(slot, n) lg_add(lg, (slot), (uint32_t)(n))
+#define LG_ARG , lg
+#else
+#define LG(slot, n) ((void)0)
+#define LG_ARG
+#endif
+#ifdef RT_LEDGER_MARKS          /* block boundaries as comments in the ISA of an otherwise unchanged product kernel (tools/ledger_static.py) */
+#define LGM(name) asm volatile("; LEDGER_MARK " name)
+#else
+#define LGM(name) ((void)0)
+#endif
+#if defined(RT_LEDGER) && RT_LEDGER >= 2
+#define LGT0() const unsigned long long lg_t0 = __builtin_amdgcn_s_memtime()
+#define LGT1(slot) LG((slot), (uint32_t)((__builtin_amdgcn_s_memtime() - lg_t0) >> 4))
+#else
+#define LGT0() ((void)0)
+#define LGT1(slot) ((void)0)
+#endif
+
 __device__ __forceinline__ float4 ld4(const float *base, int idx4) {
   return reinterpret_cast<const float4 *>(base)[idx4];
 }
@@ -1029,28 +1076,33 @@ __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *
   const int k0 = (int)__builtin_ctz(surv);
   const int e0 = as_i(slab_entry_ordered(r, bs, nbase, k0, nx, ny, nz, hit_t));
   const uint32_t f0 = 1u - (((uint32_t)e0 + 0x00800000u) >> 31);                   // 1 iff e0 is finite (a candidate)
+  LGM("nfew_ret1");
   if (n == 1) return (uint32_t)k0 | (f0 << 24);
   surv &= surv - 1u;
   const int k1 = (int)__builtin_ctz(surv);
   const int e1 = as_i(slab_entry_ordered(r, bs, nbase, k1, nx, ny, nz, hit_t));
   const uint32_t f1 = 1u - (((uint32_t)e1 + 0x00800000u) >> 31);
+  LGM("nfew_two");
   if (n == 2) {
     const bool swap = e1 < e0;                                                     // ties: lowest index first
     const uint32_t first = swap ? (uint32_t)k1 : (uint32_t)k0, second = swap ? (uint32_t)k0 : (uint32_t)k1;
     return first | (second << 3) | ((f0 + f1) << 24);
   }
+  LGM("nfew_ret2");
   surv &= surv - 1u;
   const int k2 = (int)__builtin_ctz(surv);
   const int e2 = as_i(slab_entry_ordered(r, bs, nbase, k2, nx, ny, nz, hit_t));
   const uint32_t f2 = 1u - (((uint32_t)e2 + 0x00800000u) >> 31);
   int e3 = 0x7F800000, k3 = 0;
   uint32_t f3 = 0;
+  LGM("nfew_four_begin");
   if (n == 4) {
     surv &= surv - 1u;
     k3 = (int)__builtin_ctz(surv);
       e3 = as_i(slab_entry_ordered(r, bs, nbase, k3, nx, ny, nz, hit_t));
     f3 = 1u - (((uint32_t)e3 + 0x00800000u) >> 31);
   }
+  LGM("nfew_four_end");
   const int e[4] = {e0, e1, e2, e3};
   const int kk[4] = {k0, k1, k2, k3};
   int rank[4] = {0, 1, 2, 3};
@@ -1097,15 +1149,25 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
                                                  const int lane, const int n_lds, const int pyr_nodes, const int pyr_off,
                                                  const int leaf_level, const int exit_lanes, const int n_trav0, const Ray3 &ray,
                                                  const bool is_cam, int &phase, int &level, int &node, int &child, uint32_t &cur,
-                                                 uint32_t &dirty, uint32_t &live, HitRec &hit, uint32_t &w_nodes, uint32_t &w_leaves) {
+                                                 uint32_t &dirty, uint32_t &live, HitRec &hit, uint32_t &w_nodes, uint32_t &w_leaves,
+                                                 uint32_t *lg = nullptr) {
+  LG(LG_TRAV_CALLS, 1);
   for (;;) {
+    LGM("round_begin");
     const unsigned long long maskN = __ballot(phase == PH_NODE);
     const int nN = (int)__popcll(maskN);
     const int nL = (int)__popcll(__ballot(phase == PH_LEAF));
     if (nN + nL == 0 || n_trav0 - (nN + nL) >= exit_lanes) break;
+    LG(LG_ROUND_X, 1);
 
     if (nL >= nN) {
       // ----- LEAF -----
+      LGT0();
+      LGM("leaf_begin");
+      LG(LG_LEAF_X, 1); LG(LG_LEAF_L, nL);
+#ifdef RT_LEDGER
+      LG(LG_LEAF_CAM, __popcll(__ballot(phase == PH_LEAF && is_cam)));
+#endif
       w_leaves += (uint32_t)nL;
 #if RT_LEAF_PAIRS
       {
@@ -1122,8 +1184,12 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
         phase = PH_POP;
       }
 #endif
+      LGM("leaf_end");
+      LGT1(LG_CYC_LEAF);
     } else {
       // ----- NODE -----
+      LGT0();
+      LGM("node_begin");
       w_nodes += (uint32_t)nN;
       const bool all_fast = (maskN & __ballot(!ray.fast)) == 0ull;
       // camera rays of this tile about to enter the same node: test only the children their pyramid can touch.  When
@@ -1137,6 +1203,7 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
         if (LDSN && all_fast && camN != 0ull) {
           const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(camN));
           const int nG = (int)__popcll(camN & __ballot(child == c0));
+          LG(LG_PYRCHK_X, 1);
           if (c0 < pyr_nodes && nG * RT_PYR_DEN >= nN * RT_PYR_NUM && nG >= RT_PYR_MIN) {
             // the mask depends on (tile, node) only and the tile's camera rays keep coming back to the same nodes
             float *pyr = lds_at(smem, pyr_off);
@@ -1145,12 +1212,25 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
             if ((ce >> 8) == (uint32_t)c0 + 1u) {
               surv = 0xFFu & ~ce;
             } else {
+              LG(LG_CULLMASK_X, 1);
+              LGM("cullmask_begin");
               const uint32_t cull = pyramid_cull_mask(lds_nodes, pyr, c0);
               if (lane_now() == 0) *slot = (((uint32_t)c0 + 1u) << 8) | cull;
               surv = 0xFFu & ~cull;
+              LGM("cullmask_end");
             }
             if (__popc(surv) > 4) surv = 0xFFFFu;
-            else { in_blk = phase == PH_NODE && is_cam && child == c0; w_nodes -= (uint32_t)(nN - nG); }
+            else {
+              in_blk = phase == PH_NODE && is_cam && child == c0; w_nodes -= (uint32_t)(nN - nG);
+#ifdef RT_LEDGER
+              {
+                const int ns = (int)__popc(surv);         // (constant slots: a dynamic index would put the ledger into scratch)
+                LG(LG_NFEW0_X, ns == 0); LG(LG_NFEW1_X, ns == 1); LG(LG_NFEW2_X, ns == 2); LG(LG_NFEW3_X, ns == 3); LG(LG_NFEW4_X, ns == 4);
+                LG(LG_NFEW0_L, ns == 0 ? nG : 0); LG(LG_NFEW1_L, ns == 1 ? nG : 0); LG(LG_NFEW2_L, ns == 2 ? nG : 0);
+                LG(LG_NFEW3_L, ns == 3 ? nG : 0); LG(LG_NFEW4_L, ns == 4 ? nG : 0); LG(LG_NODE_WAIT_L, nN - nG);
+              }
+#endif
+            }
           }
         }
       }
@@ -1162,17 +1242,34 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
         node = child;
         level += 1;
         if (PYRAMID && surv <= 0xFFu) {
+          LGM("nfew_begin");
           cur = surv ? node_enter_few(ray, lds_nodes, node, surv, hit.t) : 0u;
+          LGM("nfew_end");
         } else if (all_fast) {
-          if (LDSN && __ballot(node >= n_lds) == 0) cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
-          else cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+          if (LDSN && __ballot(node >= n_lds) == 0) {
+            LG(LG_NFULL_X, 1); LG(LG_NFULL_L, nN);
+#ifdef RT_LEDGER
+            LG(LG_NFULL_CAM, __popcll(maskN & __ballot(is_cam)));
+#endif
+            LGM("nfull_begin");
+            cur = node_enter<true, NODE_LDS_ORDERED>(P, ray, node, hit.t, lds_nodes);
+            LGM("nfull_end");
+          } else {
+            LG(LG_NGLOB_X, 1); LG(LG_NGLOB_L, nN);
+            LGM("nglob_begin");
+            cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
+            LGM("nglob_end");
+          }
         } else if (ray.fast) {
+          LGM("nexact_begin");
+          LG(LG_NEXACT_X, 1); LG(LG_NEXACT_L, nN);
           // a block that holds a ray that is not NaN-free (axis-aligned, 0 * inf): every lane takes the form ITS ray is
           // entitled to -- the two round differently under contract v2 -- in two passes over the block's lanes
           cur = node_enter<true, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
         } else {
           cur = node_enter<false, NODE_GLOBAL>(P, ray, node, hit.t, lds_nodes);
         }
+        LGM("node_entered");
         dirty &= ~(1u << level);
         if (cur >> 24) {
           child = 8 * node + 1 + (int)(cur & 7u);
@@ -1182,12 +1279,27 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
           phase = PH_POP;
         }
       }
+      LGM("node_end");
+      LGT1(LG_CYC_NODE);
     }
 
     // ----- pops: every lane that just finished a block takes its next child / goes up -----
+    LGT0();
+    LGM("pop_begin");
     while (__any(phase == PH_POP)) {
+#ifdef RT_LEDGER
+      {
+        const unsigned long long mp = __ballot(phase == PH_POP);
+        LG(LG_POP_X, 1); LG(LG_POP_L, __popcll(mp)); LG(LG_POP_CAM, __popcll(mp & __ballot(is_cam)));
+        const unsigned long long mu = mp & __ballot((cur >> 24) == 0 || level < 0);
+        LG(LG_POP_UP_L, __popcll(mu)); LG(LG_POP_UP_X, mu != 0ull);
+      }
+      bool lg_retest = false;
+#endif
+      LGM("pop_iter_begin");
       if (phase == PH_POP) {
         uint32_t cnt = cur >> 24;
+        LGM("pop_up_begin");
         if (cnt == 0 || level < 0) {
           // go up to the nearest level that still has children to visit -- in one step: the k-th ancestor of node n in the
           // implicit 8-ary tree is (n - (8^k - 1)/7) >> 3k, and (8^k - 1)/7 is k ones 3 bits apart
@@ -1204,10 +1316,15 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
             cnt = cur >> 24;
           }
         }
+        LGM("pop_up_end");
         if (phase == PH_POP) {
           int j = (int)(cur & 7u);
           cur = ((cur >> 3) & 0x1FFFFFu) | ((cnt - 1u) << 24);
           bool go = true;
+#ifdef RT_LEDGER
+          lg_retest = ((dirty >> level) & 1u) != 0;
+#endif
+          LGM("pop_retest_begin");
           if ((dirty >> level) & 1u) {
             float dj;
             if (LDSN && node < n_lds) {
@@ -1219,19 +1336,30 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
               const float sy = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)), ray.o.y, ray.inv_y, bs.y);
               const float sz = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)), ray.o.z, ray.inv_z, bs.z);
               dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
+              LGM("pop_rare_begin");
               if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
+              LGM("pop_rare_end");
             } else {
+              LGM("pop_glob_begin");
               dj = slab_entry_child_any(P.nodes + (size_t)node * 48 + j, ray);
+              LGM("pop_glob_end");
             }
             if (!(dj < hit.t)) { cur = 0; go = false; }      // raytracer.c:470-472
           }
+          LGM("pop_retest_end");
           if (go) {
             child = 8 * node + 1 + j;
             phase = (level == leaf_level) ? PH_LEAF : PH_NODE;
           }
         }
       }
+      LGM("pop_iter_end");
+#ifdef RT_LEDGER
+      { const unsigned long long mr = __ballot(lg_retest); LG(LG_POP_RETEST_L, __popcll(mr)); LG(LG_POP_RETEST_X, mr != 0ull); }
+#endif
     }
+    LGM("pop_end");
+    LGT1(LG_CYC_POP);
   }
 }
 

@@ -53,6 +53,18 @@
 //    loop.  Path state (tint, emission, RNG, pixel) is untouched inside the inner loop, the block choice there is
 //    two ballots, and the counters are wave-level scalars.
 
+#ifdef RT_LEDGER
+#define RT_LEDGER_WAVES 8192
+__device__ uint32_t g_ledger[RT_LEDGER_WAVES * 64];      // block ledger: one row of LG_* slots per wave (rt_dev.hip.h)
+__global__ void rt_ledger_reduce_kernel(unsigned long long *counters) {
+  const int slot = threadIdx.x;
+  if (slot >= LG_N || slot >= 64) return;
+  unsigned long long sum = 0ull;
+  for (int w = 0; w < RT_LEDGER_WAVES; w++) sum += g_ledger[w * 64 + slot];
+  counters[8 + slot] = sum;
+}
+#endif
+
 template <int WAVES, bool LDSN, int MIN_WAVES_PER_SIMD, bool SHORT_DIV>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel_stream(RT_KParams P) {
   extern __shared__ float4 smem[];
@@ -86,8 +98,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   // wave-level counters (scalar registers)
   uint32_t w_paths = 0, w_rays = 0, w_nodes = 0, w_leaves = 0, w_shades = 0, w_bgs = 0, w_tex = 0;
   const unsigned long long t_wave_start = cold_args()->wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // RT_WAVE_TIMES only
-#ifdef RT_EXP_NODESTATS
-  uint32_t xs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RT_LEDGER
+  uint32_t *lg = g_ledger + (size_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave) * 64;
+  const unsigned long long lg_wave_t0 = __builtin_amdgcn_s_memtime();
 #endif
   uint32_t n_tiles_done = 0;
   unsigned long long t_last_grab = 0ull;
@@ -106,6 +119,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 
   for (;;) {
     // ---------------- take a tile: own one from the queue, or join one that still has units ----------------
+    LGT0();
+    LGM("tile_begin");
     int tile_idx = -1;
     if (queue_open) {
       RT_KArgs A = cold_args();
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     if (tile_idx < 0) {
       if (steal_tries >= RT_STEAL_TRIES) break;
       steal_tries += 1;
+      LG(LG_JOIN_X, 1);
       // two-level scan with agent-scope loads: groups of 64 tiles that still have an open tile (open_groups[g] > 0),
       // then the tiles of one such group.  Start positions differ per wave so that joiners spread over the open tiles.
       RT_KArgs A = cold_args();
@@ -246,6 +262,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       tile_root_miss = __ballot(may_hit) == 0ull;
     }
     const uint32_t rays_before = w_rays;
+    LG(LG_TILE_X, 1);
+    LGM("tile_end");
+    LGT1(LG_CYC_TILE);
 
     // ---------------- per-lane state ----------------
     int   phase = PH_NEED;
@@ -273,6 +292,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     for (;;) {
       // ================= S: shade the hits, environment for the misses, start new paths =================
       {
+        LGT0();
+        LGM("s_begin");
+        LG(LG_S_ITER, 1);
         LaneCounters cn;
         cn.rays = cn.nodes = cn.leaves = cn.shades = cn.bgs = cn.textured = cn.paths = 0;
         bool  done = false, start = false, fresh = false;
@@ -283,12 +305,17 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         SP.tris = A->tris; SP.mats = A->mats; SP.textures = A->textures; SP.texels = A->texels;
         SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
         // ---- environment for the paths that left the scene ----
+#ifdef RT_LEDGER
+        { const int n_env = (int)__popcll(__ballot(phase == PH_MISS)); LG(LG_ENV_X, n_env != 0); LG(LG_ENV_L, n_env); }
+#endif
+        LGM("env_begin");
         if (phase == PH_MISS) {
           cn.bgs = 1;
           rt_v3 bg = background_lookup(SP, dir);
           radiance = rt_v3_mul_add(bg, tint, emis);
           done = true;
         }
+        LGM("env_end");
         // ---- hits: shade them now, or park them until a dense shade block can be made of them ----
         // A shade block costs ~2 200 instructions whatever the number of lanes in it, and hits arrive ~34 at a time.  While
         // the tile still hands out paths, the hits of a sparse S block are PARKED (18 dwords of path state per hit into the
@@ -305,6 +332,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           uint32_t *pk = park + (size_t)__builtin_amdgcn_readfirstlane(wave_id) * (RT_PARK_FIELDS * RT_PARK_CAP);    // (scalar base)
           if (!tile_open || h + back >= RT_PARK_DENSE || n_parked + h > RT_PARK_CAP) {
             if (back > 0) {
+              LG(LG_PLOAD_X, 1); LG(LG_PLOAD_L, back);
+              LGM("pload_begin");
               if (done) {                                               // (an environment lane is idle once its sample is added)
                 unsigned long long *ap = reinterpret_cast<unsigned long long *>(lds_at(smem, acc_off) + pix * 6);
                 atomicAdd(ap + 0, accum_quantize_dev(radiance.x));
@@ -330,8 +359,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                 phase = PH_HIT;
               }
               n_parked -= back;
+              LGM("pload_end");
             }
           } else if (h > 0) {
+            LG(LG_PSTORE_X, 1); LG(LG_PSTORE_L, h);
+            LGM("pstore_begin");
             shade_now = false;
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mHit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mHit, 0u));
             if (phase == PH_HIT) {
@@ -350,12 +382,22 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
               phase = PH_NEED;
             }
             n_parked += h;
+            LGM("pstore_end");
           }
         }
+#ifdef RT_LEDGER
+        { const int n_sh = (int)__popcll(__ballot(phase == PH_HIT && shade_now)); LG(LG_SHADE_X, n_sh != 0); LG(LG_SHADE_L, n_sh); }
+#endif
+        LGM("shade_begin");
         if (phase == PH_HIT && shade_now) {
           done = shade_hit(SP, hit, org, dir, tint, emis, rng, bounce, cn, radiance);
           start = !done;
         }
+        LGM("shade_end");
+#ifdef RT_LEDGER
+        { const int n_acc = (int)__popcll(__ballot(done)); LG(LG_ACCUM_X, n_acc != 0); LG(LG_ACCUM_L, n_acc); }
+#endif
+        LGM("accum_begin");
         if (done) {
           // (32-bit address arithmetic from the wave's byte offset: `acc + pix * 3` is a 64-bit multiply-add on a pointer
           // that is kept in scratch)
@@ -365,6 +407,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           atomicAdd(ap + 2, accum_quantize_dev(radiance.z));
           phase = PH_NEED;
         }
+        LGM("accum_end");
         w_shades += (uint32_t)__popcll(__ballot(cn.shades != 0));
         w_tex += (uint32_t)__popcll(__ballot(cn.textured != 0));
         w_bgs += (uint32_t)__popcll(__ballot(cn.bgs != 0));
@@ -375,7 +418,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           bool got = false;
           int  gx = 0, gy = 0, gs = 0, gp = 0;
           const int width = A->width, sample_end = A->sample_end;
+          LGM("regen_begin");
           while (need) {
+            LG(LG_REGEN_X, 1);
             if (c_next >= c_end) {
               if (u_cur + 1u < u_end) {
                 u_cur += 1u;
@@ -388,6 +433,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                 u_end = u0 + grab < n_chunks_tile ? u0 + grab : n_chunks_tile;
                 // exactly one wave receives the tile's last unit: it closes the tile in the group summary
                 if (u_end == n_chunks_tile && lane == 0) atomicSub(&A->open_groups[tile_idx >> 6], 1u);
+                LG(LG_GRAB_X, 1);
                 if (t_wave_start) t_last_grab = __builtin_amdgcn_s_memrealtime();
                 // next grab: `grab_max` units while the tile has plenty left, fewer towards its end.
                 // (A launch-wide count of the remaining units would be the better guide, but a counter that every grab
@@ -432,6 +478,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             c_next += take;
             need = __ballot(phase == PH_NEED && !got);
           }
+          LGM("regen_end");
+#ifdef RT_LEDGER
+          { const int n_pr = (int)__popcll(__ballot(got)); LG(LG_PRIM_X, n_pr != 0); LG(LG_PRIM_L, n_pr); LG(LG_REGEN_L, n_pr); }
+#endif
+          LGM("prim_begin");
           if (got) {
             pix = gp;
             bounce = 0;
@@ -448,8 +499,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
             start = true;
             fresh = true;
           }
+          LGM("prim_end");
         }
         bool skip_root = false;
+#ifdef RT_LEDGER
+        { const int n_st = (int)__popcll(__ballot(start)); LG(LG_START_X, n_st != 0); LG(LG_START_L, n_st); }
+#endif
+        LGM("start_begin");
         if (start) {                      // a new ray: traversal starts at the root (or at leaf group 0)
           ray_setup<SHORT_DIV>(ray, org, dir);
           hit.t = RT_INF; hit.tri = -1; hit.u = 0; hit.v = 0;
@@ -464,8 +520,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           skip_root = fresh && tile_root_miss && ray.fast;
           if (skip_root) phase = PH_MISS;
         }
+        LGM("start_end");
         w_rays += (uint32_t)__popcll(__ballot(start));
         w_nodes += (uint32_t)__popcll(__ballot(skip_root));
+        LGM("s_end");
+        LGT1(LG_CYC_S);
       }
 
       const int n_trav0 = (int)__popcll(__ballot(phase == PH_NODE || phase == PH_LEAF));
@@ -482,11 +541,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       // shade as soon as `drain_thresh` lanes wait
       traversal_blocks<LDSN, SHORT_DIV, true>(P, smem, lds_nodes, perm, lane, n_lds, pyr_nodes, pyr_off, leaf_level,
                                               tile_open ? thresh : drain_thresh, n_trav0, ray, bounce == 0, phase, level, node,
-                                              child, cur, dirty, live, hit, w_nodes, w_leaves);
+                                              child, cur, dirty, live, hit, w_nodes, w_leaves LG_ARG);
     }
 
     // ---------------- flush the wave's share of the tile: lane p owns pixel p ----------------
+    LGM("flush_begin");
     if (took_any) {
+      LG(LG_FLUSH_X, 1);
       int x = tile_x0 + (lane & 7), y = tile_y0 + (lane >> 3);
       unsigned long long r = acc[lane * 3 + 0], g = acc[lane * 3 + 1], b = acc[lane * 3 + 2];
       acc[lane * 3 + 0] = 0ull;
@@ -522,8 +583,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     atomicAdd(counters + CNT_SHADES, (unsigned long long)w_shades);
     atomicAdd(counters + CNT_BG, (unsigned long long)w_bgs);
     atomicAdd(counters + CNT_TEXTURED, (unsigned long long)w_tex);
-#ifdef RT_EXP_NODESTATS
-    for (int i = 0; i < 16; i++) atomicAdd(counters + 8 + i, (unsigned long long)xs[i]);
+#ifdef RT_LEDGER
+    LG(LG_CYC_WAVE, (uint32_t)((__builtin_amdgcn_s_memtime() - lg_wave_t0) >> 4));
 #endif
   }
 }
@@ -1049,8 +1110,20 @@ static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipSt
     if (e != hipSuccess) return (int)e;
     if (dev < 32) __atomic_fetch_or(&attr_devices, 1u << dev, __ATOMIC_RELAXED);
   }
+#ifdef RT_LEDGER
+  {
+    void *sym = nullptr;
+    if (n_waves > RT_LEDGER_WAVES) return (int)hipErrorInvalidValue;
+    hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_ledger));
+    if (e == hipSuccess) e = hipMemsetAsync(sym, 0, sizeof(uint32_t) * RT_LEDGER_WAVES * 64, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+#endif
   hipLaunchKernelGGL((rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>), dim3((n_waves + WAVES - 1) / WAVES),
                      dim3(WAVES * 64), smem_bytes, stream, *P);
+#ifdef RT_LEDGER
+  hipLaunchKernelGGL(rt_ledger_reduce_kernel, dim3(1), dim3(64), 0, stream, P->counters);
+#endif
   return (int)hipGetLastError();
 }
 

@@ -163,7 +163,7 @@ EXPORTED_SYMBOLS = [
 # include/rt_hip_diag.h: exported by librt_hip_diag.so only (which also exports everything above); the product library must
 # NOT carry them (tests/test_abi.py)
 DIAG_ONLY_SYMBOLS = [
-    "rt_diag_set_tokens", "rt_set_pipeline", "rt_get_pipeline", "rt_set_wavefront_capacity", "rt_get_sched_stats", "rt_get_wave_times",
+    "rt_diag_set_tokens", "rt_set_pipeline", "rt_get_pipeline", "rt_set_wavefront_capacity", "rt_get_sched_stats", "rt_get_wave_times", "rt_get_ledger",
     "rt_test_math", "rt_test_rcp_sweep", "rt_test_srgb_sweep", "rt_test_quantize_sweep", "rt_test_trace", "rt_test_trace_stream",
     "rt_test_tile_order", "rt_test_texture",
 ]

@@ -164,6 +164,7 @@ def _declare_diag(d):
     d.rt_set_wavefront_capacity.restype = None
     d.rt_get_sched_stats.argtypes = [vp]
     d.rt_get_wave_times.argtypes = [vp, C.c_int32]
+    d.rt_get_ledger.argtypes = [vp, C.c_int32]
     d.rt_diag_set_tokens.argtypes = [vp, vp, vp]
     d.rt_diag_set_tokens.restype = None
 
