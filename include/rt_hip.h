@@ -57,14 +57,26 @@ typedef struct RT_Device_Scene RT_Device_Scene;
 extern RT_Device_Scene *rt_scene_upload(Scene const *scene);
 extern void             rt_scene_release(RT_Device_Scene *dscene);
 extern void             rt_scene_invalidate(Scene const *scene);
-/* render_thread_proc() re-reads, on every frame, the dimensions and base pointers of the host Scene, its material records
- * and the descriptors of the Images they reference in full, and a bounded sample of every block of geometry and texel bytes
- * (blocks up to 4 KB in full, larger ones 8 runs of 512 bytes; tens of microseconds), and uploads again when any of that
- * changed.  An in-place edit of a few vertices or texels inside a LARGE block can escape the sample: such a host calls
- * rt_scene_invalidate().
- * rt_scene_verify() is the full comparison on demand: 1 = the cached copy still matches the host scene, 0 = it did not
- * (dropped; the next frame uploads), -1 = nothing cached for this Scene. */
+/* The reference reads the live Scene every frame (raytracer.c:596-612); a frame here renders from the cached device copy.
+ * What keeps the two equal, per frame behind render_thread_proc() / render() / rt_render_frame():
+ *  1. BEFORE the frame is enqueued (tens of microseconds): dimensions and base pointers of the host Scene, its material
+ *     records and the descriptors of their Images in full, a bounded sample of every block of geometry and texel bytes;
+ *  2. WHILE the GPU renders, on the calling thread: every byte of the BVH, the coordinate arrays, the AoS records and the
+ *     materials, the texels of images above 64 KB one word in 61.  If that differs from what was uploaded, the frame is
+ *     discarded, the scene uploaded again and the frame rendered again: an in-place edit of vertices, boxes or materials is
+ *     seen by the next frame like in the reference.  A frame of an unchanged scene waits for max(kernel, check), not for
+ *     their sum (RT_Frame_Timing.verify_ms; helmet: ~0.5 ms of host time behind a kernel of 0.6 ms or more).
+ *     rt_scene_set_static(scene, 1) switches (2) off for a host that never edits in place (or tells: rt_scene_touch).
+ *  3. rt_scene_touch(scene, begin, bytes): "I wrote these bytes" -- nodes, coordinates, AoS records, a material record or
+ *     texels of a texture / the background.  The block they belong to is patched on every device (a few texture rows, a few
+ *     leaf tiles) instead of the whole scene being uploaded again, and the stamps are refreshed: also the way to get a
+ *     single-texel edit seen that the 1-in-61 sampling of (2) can miss.  Returns 0 = patched in place, 1 = not a patchable
+ *     range (the copies were dropped, the next frame uploads), -1 = error.
+ * rt_scene_invalidate() drops the cached copies; rt_scene_verify() is the comparison of (2) on demand: 1 = the cached copy
+ * still matches the host scene, 0 = it did not (dropped; the next frame uploads), -1 = nothing cached for this Scene. */
 extern int              rt_scene_verify(Scene const *scene);
+extern int              rt_scene_touch(Scene const *scene, void const *begin, size_t bytes);
+extern void             rt_scene_set_static(Scene const *scene, i32 is_static);
 extern i64              rt_scene_device_bytes(RT_Device_Scene const *dscene);
 
 /* Camera used by rt_render_accumulate() for an explicitly uploaded scene;
@@ -163,10 +175,15 @@ extern int rt_get_counters(RT_Counters *out);
 /* Where the time of the last frame behind render_thread_proc / render / rt_render_frame went, in milliseconds.
  * Host clock: stamp = the per-frame scene check, upload = the scene upload when one was needed, enqueue = launching the
  * frame, total = the whole call.  HIP events on the frame's stream: gpu_prep = accumulator clear + the preparation kernel,
- * gpu_path = the path kernel, gpu_resolve, gpu_copy = device-to-host copy of the image.  (A multi-device frame reports
- * total_ms only.) */
+ * gpu_path = the path kernel, gpu_resolve, gpu_copy = device-to-host copy of the image.  A multi-device frame reports the
+ * SLOWEST device's prep / path / resolve times, gpu_copy = that device's tile copy to the primary GPU, the largest stamp /
+ * upload / enqueue time of any device, and gather_ms. */
 typedef struct {
   f32 stamp_ms, upload_ms, enqueue_ms, gpu_prep_ms, gpu_path_ms, gpu_resolve_ms, gpu_copy_ms, total_ms;
+  f32 verify_ms;       /* the full content check of the host scene, on the calling thread WHILE the GPU renders (rt_scene_touch) */
+  f32 gather_ms;       /* multi-device frames: waiting for the other devices' tiles + untile + copy to the caller's pixels      */
+  i32 n_devices;       /* GPUs the frame was spread over                                                                         */
+  i32 slowest_device;  /* multi-device frames: the slot whose prep / path / resolve / copy times are reported above              */
 } RT_Frame_Timing;
 extern int rt_get_frame_timing(RT_Frame_Timing *out);
 

@@ -19,6 +19,11 @@ extern "C" {
  * token addresses.  NULL keeps the current one. */
 extern void rt_diag_set_tokens(void *disney_proc, void *debug_proc, void *background_proc);
 
+/* Fault injection for the multi-device frame (tests/test_gpu_multi_device.py): no_peer != 0 = treat every device as if peer
+ * access to the primary GPU had been refused (its tiles are staged through pinned host memory); failing_slot >= 0 = that
+ * device slot fails its part of the next frames (-1 = none). */
+extern void rt_diag_multi_fault(i32 no_peer, i32 failing_slot);
+
 /* 0 (default): the tile-stream path kernel.  1: the wavefront pipeline (camera / shade / trace kernels joined by record
  * queues in HBM, csrc/rt_wavefront.hip): the same images and counters bit for bit, measured slower;
  * selectable for measurements.  rt_set_wavefront_capacity(): camera-ray hits its queues hold per pass (default 96 M). */

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -154,12 +155,16 @@ static Config config() {
   return config_locked();
 }
 
+static void remap_device_slots();
 extern "C" int rt_set_devices(i32 n_devices, i32 rehearse) {
   if (n_devices < 1 || n_devices > RT_MAX_DEVICES) return rt_fail("rt_set_devices: %d outside [1, %d]", n_devices, RT_MAX_DEVICES);
-  std::lock_guard<std::mutex> lock(g_cfg_mutex);
-  Config &c = config_locked();
-  c.devices = n_devices;
-  c.rehearse = rehearse != 0;
+  {
+    std::lock_guard<std::mutex> lock(g_cfg_mutex);
+    Config &c = config_locked();
+    c.devices = n_devices;
+    c.rehearse = rehearse != 0;
+  }
+  remap_device_slots();          // a slot that was mapped to another GPU under the old configuration starts over
   return 0;
 }
 
@@ -188,7 +193,8 @@ struct RT_Device_Scene;
 
 struct FrameTiming {          // the most recent frame through render_thread_proc / render / rt_render_frame
   float stamp_ms = 0, upload_ms = 0, enqueue_ms = 0, gpu_prep_ms = 0, gpu_path_ms = 0, gpu_resolve_ms = 0, gpu_copy_ms = 0,
-        total_ms = 0;
+        total_ms = 0, verify_ms = 0, gather_ms = 0;
+  int   n_devices = 1, slowest_device = 0;
 };
 
 struct Workspace {
@@ -201,6 +207,9 @@ struct Workspace {
   size_t              tiles_bytes = 0;
   uint8_t            *all_tiles = nullptr;    // slot 0: the tiles of every device, rank-major
   size_t              all_tiles_bytes = 0;
+  uint8_t            *tiles_host = nullptr;   // pinned: a device without peer access to slot 0 stages its tiles here
+  size_t              tiles_host_bytes = 0;
+  unsigned long long *counters_host = nullptr;   // pinned: ray counters of a multi-device frame, copied asynchronously
   // HIP event pairs around every path-kernel launch since the last timing reset
   std::vector<hipEvent_t> ev0, ev1;
   size_t              n_timed = 0;
@@ -219,6 +228,7 @@ struct DevPartition {
 struct Device {
   int        slot = 0, phys = 0;
   bool       ready = false;
+  bool       peer_ok = true;                  // slots >= 1: direct copies into slot 0's memory are possible (xGMI peer access)
   int        num_cus = 0;
   std::mutex mutex;                           // serialises frames, the scene cache and the workspace of this device
   Workspace  ws;
@@ -271,10 +281,13 @@ static int ensure_device(Device &D) {            // D.mutex held (or single-thre
   if (D.slot != 0 && D.phys != g_primary) {
     // this device sends its tiles into device 0's buffer: direct xGMI copies when peer access can be enabled, staged ones otherwise
     int can = 0;
+    D.peer_ok = false;
     if (hipDeviceCanAccessPeer(&can, D.phys, g_primary) == hipSuccess && can) {
       hipError_t pe = hipDeviceEnablePeerAccess(g_primary, 0);
-      if (pe != hipSuccess) (void)hipGetLastError();      // (already enabled, or refused: hipMemcpyPeerAsync still works)
+      if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) D.peer_ok = true;
+      if (pe != hipSuccess) (void)hipGetLastError();
     }
+    // (refused: the tiles go through a pinned host buffer, render_frame_multi)
   }
   D.ready = true;
   return 0;
@@ -358,6 +371,10 @@ struct RT_Device_Scene {
   uint64_t     stamp = 0;
   std::vector<const void *> mat_ptrs;     // distinct shader.data pointers, upload order
   std::vector<int32_t>      mat_first_tri;   // a triangle that uses mat_ptrs[k]
+  // what rt_scene_touch() needs to patch the copy in place
+  std::unordered_map<uint64_t, int> mat_map;            // (shader.data, kind) -> material id
+  std::vector<const Image *>        tex_sources;        // Image of texture k (pool order; the background is one of them)
+  std::vector<RT_DTexture>          tex_descs;          // its slot in the texel pool
   // launch state of this device scene: two device scenes can have launches in flight on two streams at once
   unsigned long long *counters = nullptr;      // RT_N_COUNTERS
   uint32_t           *work_head = nullptr;
@@ -637,6 +654,49 @@ static float int_bits(int32_t i) {
   return f;
 }
 
+// one leaf tile: 9 rows x 8: vertex a, then the edges b - a and c - a (raytracer.c:115-122 computes them per visit; the fp32
+// subtraction done here gives the same bits)
+static void build_leaf_tile(const Triangles &T, int g, float *l) {
+  for (int k = 0; k < 8; k++) {
+    int i = g * 8 + k;
+    volatile float e;     // keep every difference a plain IEEE fp32 subtraction
+    l[0 * 8 + k] = T.x[0][i];
+    e = T.x[1][i] - T.x[0][i]; l[1 * 8 + k] = e;
+    e = T.x[2][i] - T.x[0][i]; l[2 * 8 + k] = e;
+    l[3 * 8 + k] = T.y[0][i];
+    e = T.y[1][i] - T.y[0][i]; l[4 * 8 + k] = e;
+    e = T.y[2][i] - T.y[0][i]; l[5 * 8 + k] = e;
+    l[6 * 8 + k] = T.z[0][i];
+    e = T.z[1][i] - T.z[0][i]; l[7 * 8 + k] = e;
+    e = T.z[2][i] - T.z[0][i]; l[8 * 8 + k] = e;
+  }
+}
+static void leaf_tile_max_edge(const float *l, float &max_edge) {
+  for (int row : {1, 2, 4, 5, 7, 8})
+    for (int k = 0; k < 8; k++) {
+      float m = fabsf(l[row * 8 + k]);
+      if (!(m <= max_edge)) max_edge = m;          // a NaN sticks (every later comparison is false as well)
+    }
+}
+// the 28-float shading record of triangle i (rt_device.h) with material id `mat`
+static void build_tri_record(const Triangle_AOS &a, int mat, float *r) {
+  r[0] = a.normal.x;    r[1] = a.normal.y;    r[2] = a.normal.z;    r[3] = int_bits(mat < 0 ? 0 : mat);
+  r[4] = a.normal_a.x;  r[5] = a.normal_a.y;  r[6] = a.normal_a.z;  r[7] = a.tex_coords_a.x;
+  r[8] = a.normal_b.x;  r[9] = a.normal_b.y;  r[10] = a.normal_b.z; r[11] = a.tex_coords_a.y;
+  r[12] = a.normal_c.x; r[13] = a.normal_c.y; r[14] = a.normal_c.z; r[15] = a.tex_coords_b.x;
+  r[16] = a.tangent.x;  r[17] = a.tangent.y;  r[18] = a.tangent.z;  r[19] = a.tex_coords_b.y;
+  r[20] = a.bitangent.x; r[21] = a.bitangent.y; r[22] = a.bitangent.z; r[23] = a.tex_coords_c.x;
+  r[24] = a.tex_coords_c.y; r[25] = 0.0f; r[26] = 0.0f; r[27] = 0.0f;
+}
+static void build_material_row(const PBR_Shader_Data *d, int ta, int tn, int tm, int te, int kind, float *m) {
+  const float row[20] = {d->base_color.x, d->base_color.y, d->base_color.z, d->roughness,
+                         d->emission.x, d->emission.y, d->emission.z, d->metalness,
+                         d->normal_map_strength, d->sheen, d->sheen_tint, d->anisotropic_strength,
+                         int_bits(ta), int_bits(tn), int_bits(tm), int_bits(te),
+                         int_bits(kind), 0.0f, 0.0f, 0.0f};
+  memcpy(m, row, sizeof row);
+}
+
 static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
   if (ensure_device(D) != 0) return nullptr;
   if (!scene) { rt_fail("rt_scene_upload: scene is NULL"); return nullptr; }
@@ -704,56 +764,25 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
           return nullptr;
         }
         mat = (int)(mats.size() / 20);
-        float m[20] = {d->base_color.x, d->base_color.y, d->base_color.z, d->roughness,
-                       d->emission.x, d->emission.y, d->emission.z, d->metalness,
-                       d->normal_map_strength, d->sheen, d->sheen_tint, d->anisotropic_strength,
-                       int_bits(ta), int_bits(tn), int_bits(tm), int_bits(te),
-                       int_bits(kind), 0.0f, 0.0f, 0.0f};
+        float m[20];
+        build_material_row(d, ta, tn, tm, te, kind, m);
         mats.insert(mats.end(), m, m + 20);
         mat_map[key] = mat;
         mat_ptrs.push_back(a.shader.data);
         mat_first_tri.push_back(i);
       }
     }
-    float *r = &tris[(size_t)i * 28];
-    r[0] = a.normal.x;    r[1] = a.normal.y;    r[2] = a.normal.z;    r[3] = int_bits(mat < 0 ? 0 : mat);
-    r[4] = a.normal_a.x;  r[5] = a.normal_a.y;  r[6] = a.normal_a.z;  r[7] = a.tex_coords_a.x;
-    r[8] = a.normal_b.x;  r[9] = a.normal_b.y;  r[10] = a.normal_b.z; r[11] = a.tex_coords_a.y;
-    r[12] = a.normal_c.x; r[13] = a.normal_c.y; r[14] = a.normal_c.z; r[15] = a.tex_coords_b.x;
-    r[16] = a.tangent.x;  r[17] = a.tangent.y;  r[18] = a.tangent.z;  r[19] = a.tex_coords_b.y;
-    r[20] = a.bitangent.x; r[21] = a.bitangent.y; r[22] = a.bitangent.z; r[23] = a.tex_coords_c.x;
-    r[24] = a.tex_coords_c.y;
+    build_tri_record(a, mat, &tris[(size_t)i * 28]);
   }
   if (mats.empty()) mats.resize(20, 0.0f);
 
-  // leaf tiles: 9 rows x 8 per group: vertex a, then the edges b-a and c-a (raytracer.c:115-122 computes
-  // them per visit; the fp32 subtraction done here gives the same bits)
+  // leaf tiles (build_leaf_tile)
   const int n_groups = n / 8;
   std::vector<float> leaves((size_t)n_groups * 72);
-  for (int g = 0; g < n_groups; g++) {
-    float *l = &leaves[(size_t)g * 72];
-    for (int k = 0; k < 8; k++) {
-      int i = g * 8 + k;
-      volatile float e;     // keep every difference a plain IEEE fp32 subtraction
-      l[0 * 8 + k] = T.x[0][i];
-      e = T.x[1][i] - T.x[0][i]; l[1 * 8 + k] = e;
-      e = T.x[2][i] - T.x[0][i]; l[2 * 8 + k] = e;
-      l[3 * 8 + k] = T.y[0][i];
-      e = T.y[1][i] - T.y[0][i]; l[4 * 8 + k] = e;
-      e = T.y[2][i] - T.y[0][i]; l[5 * 8 + k] = e;
-      l[6 * 8 + k] = T.z[0][i];
-      e = T.z[1][i] - T.z[0][i]; l[7 * 8 + k] = e;
-      e = T.z[2][i] - T.z[0][i]; l[8 * 8 + k] = e;
-    }
-  }
   float max_edge = 0.0f;
   for (int g = 0; g < n_groups; g++) {
-    const float *l = &leaves[(size_t)g * 72];
-    for (int row : {1, 2, 4, 5, 7, 8})
-      for (int k = 0; k < 8; k++) {
-        float m = fabsf(l[row * 8 + k]);
-        if (!(m <= max_edge)) max_edge = m;          // a NaN sticks (every later comparison is false as well)
-      }
+    build_leaf_tile(T, g, &leaves[(size_t)g * 72]);
+    leaf_tile_max_edge(&leaves[(size_t)g * 72], max_edge);
   }
 
   std::vector<float> nodes;
@@ -796,6 +825,9 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
   d->n_textures = (int32_t)pool.descs.size();
   d->mat_ptrs = mat_ptrs;
   d->mat_first_tri = mat_first_tri;
+  d->mat_map = mat_map;
+  d->tex_sources = pool.sources;
+  d->tex_descs = pool.descs;
   d->stamp = scene_stamp(scene, d->mat_ptrs, d->mat_first_tri);
   return d;
 }
@@ -836,21 +868,179 @@ extern "C" void rt_scene_invalidate(Scene const *scene) {
 
 extern "C" i64 rt_scene_device_bytes(RT_Device_Scene const *dscene) { return dscene ? dscene->bytes : 0; }
 
+// ---- in-place edits of a resident scene ------------------------------------------------------------------------------------
+// The reference reads the live Scene every frame (raytracer.c:596-612).  Here a frame renders from the device copy, and
+// three things keep the two equal:
+//  1. the sampled stamp (scene_stamp) before the frame is enqueued: rebuilt / reloaded / re-materialed scenes, microseconds;
+//  2. the FULL check (scene_fingerprint: every byte of the BVH, the coordinate arrays, the AoS records and the materials, the
+//     texels of large images one word in 61) computed by the calling thread WHILE the GPU renders the frame; if it differs
+//     from the one taken at upload the frame is thrown away, the scene uploaded again and the frame rendered again -- a
+//     frame on an unchanged scene pays nothing but host time hidden behind its own kernel.  rt_scene_set_static(scene, 1)
+//     turns this off for a host that promises not to edit in place (or that calls rt_scene_touch / rt_scene_invalidate);
+//  3. rt_scene_touch(scene, begin, bytes): "I wrote these bytes" -- the one block they belong to is patched on every device
+//     (a few texture rows, a few leaf tiles ...) instead of 80 MB being uploaded again; this is also what catches a
+//     single-texel edit that the 1-in-61 sampling of (2) can miss.
+static std::mutex g_static_mutex;
+static std::unordered_map<const Scene *, bool> g_static_scenes;
+extern "C" void rt_scene_set_static(Scene const *scene, i32 is_static) {
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (is_static) g_static_scenes[scene] = true;
+  else g_static_scenes.erase(scene);
+}
+static bool scene_is_static(Scene const *scene) {
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  return g_static_scenes.count(scene) != 0;
+}
+
+static bool range_in(const void *begin, size_t bytes, const void *block, size_t block_bytes, size_t *off) {
+  const uintptr_t b = (uintptr_t)begin, k = (uintptr_t)block;
+  if (!block || b < k || b + bytes > k + block_bytes) return false;
+  *off = (size_t)(b - k);
+  return true;
+}
+
+// Patches the device copy `d` (device D current, D.mutex held) for host bytes [begin, begin + bytes).  1 = patched,
+// 0 = the range is not something that can be patched (the caller drops the copy), -1 = HIP error.
+static int touch_device_scene(RT_Device_Scene *d, Scene const *scene, const void *begin, size_t bytes) {
+  const Triangles &T = scene->triangles;
+  const int n = (int)T.len;
+  size_t off = 0;
+  if ((int32_t)scene->bvh.nodes.len != d->n_nodes || n != d->n_triangles || (int32_t)scene->bvh.depth != d->depth) return 0;
+  // BVH nodes: stored as they are
+  if (d->n_nodes > 0 && range_in(begin, bytes, scene->bvh.nodes.data, (size_t)d->n_nodes * sizeof(BVH_Node), &off)) {
+    const size_t n0 = off / sizeof(BVH_Node), n1 = (off + bytes + sizeof(BVH_Node) - 1) / sizeof(BVH_Node);
+    const float *src = (const float *)scene->bvh.nodes.data;
+    for (size_t nd = n0; nd < n1; nd++)
+      for (int k = 0; k < 24; k++)
+        if (!(src[nd * 48 + k] <= src[nd * 48 + 24 + k])) d->boxes_ordered = false;
+    HIP_TRY(hipMemcpy(d->nodes + n0 * 48, src + n0 * 48, (n1 - n0) * sizeof(BVH_Node), hipMemcpyHostToDevice));
+    return 1;
+  }
+  // coordinate arrays: the leaf tiles of the touched triangles
+  for (int k = 0; k < 3; k++) {
+    const float *arrs[3] = {T.x[k], T.y[k], T.z[k]};
+    for (const float *arr : arrs) {
+      if (!range_in(begin, bytes, arr, (size_t)n * 4, &off)) continue;
+      const int g0 = (int)(off / 4) / 8, g1 = (int)((off + bytes + 3) / 4 + 7) / 8;
+      std::vector<float> tiles((size_t)(g1 - g0) * 72);
+      for (int g = g0; g < g1; g++) {
+        build_leaf_tile(T, g, &tiles[(size_t)(g - g0) * 72]);
+        leaf_tile_max_edge(&tiles[(size_t)(g - g0) * 72], d->max_edge);        // (the bound can only grow: conservative)
+      }
+      HIP_TRY(hipMemcpy(d->leaves + (size_t)g0 * 72, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+      return 1;
+    }
+  }
+  // AoS records: the shading records of the touched triangles (their materials must be known ones)
+  if (range_in(begin, bytes, T.aos, (size_t)n * sizeof(Triangle_AOS), &off)) {
+    const int i0 = (int)(off / sizeof(Triangle_AOS)), i1 = (int)((off + bytes + sizeof(Triangle_AOS) - 1) / sizeof(Triangle_AOS));
+    std::vector<float> recs((size_t)(i1 - i0) * 28);
+    for (int i = i0; i < i1; i++) {
+      const Triangle_AOS &a = T.aos[i];
+      int mat = -1;
+      if (a.shader.proc != nullptr) {
+        int kind = a.shader.proc == g_tok_disney ? RT_MAT_DISNEY : a.shader.proc == g_tok_debug ? RT_MAT_DEBUG : -1;
+        if (kind < 0 || !a.shader.data) return 0;
+        auto it = d->mat_map.find((uint64_t)(uintptr_t)a.shader.data * 2u + (uint64_t)kind);
+        if (it == d->mat_map.end()) return 0;                          // a material the copy does not have: upload again
+        mat = it->second;
+      }
+      build_tri_record(a, mat, &recs[(size_t)(i - i0) * 28]);
+    }
+    HIP_TRY(hipMemcpy(d->tris + (size_t)i0 * 28, recs.data(), recs.size() * 4, hipMemcpyHostToDevice));
+    return 1;
+  }
+  // a material record (its texture pointers must still be Images of the pool)
+  for (size_t k = 0; k < d->mat_ptrs.size(); k++) {
+    if (!range_in(begin, bytes, d->mat_ptrs[k], sizeof(PBR_Shader_Data), &off)) continue;
+    const PBR_Shader_Data *m = (const PBR_Shader_Data *)d->mat_ptrs[k];
+    auto tex = [&](Image const *img) -> int {
+      if (!img) return -1;
+      for (size_t t = 0; t < d->tex_sources.size(); t++) if (d->tex_sources[t] == img) return (int)t;
+      return -2;
+    };
+    const int ta = tex(m->texture_albedo), tn = tex(m->texture_normal), tm = tex(m->texture_metal_roughness), te = tex(m->texture_emission);
+    if (ta == -2 || tn == -2 || tm == -2 || te == -2) return 0;
+    bool any = false;
+    for (auto &kv : d->mat_map) {                                        // the record may serve both kinds
+      if ((const void *)(uintptr_t)(kv.first / 2u) != d->mat_ptrs[k]) continue;
+      float row[20];
+      build_material_row(m, ta, tn, tm, te, (int)(kv.first & 1u), row);
+      HIP_TRY(hipMemcpy(d->mats + (size_t)kv.second * 20, row, sizeof row, hipMemcpyHostToDevice));
+      any = true;
+    }
+    return any ? 1 : 0;
+  }
+  // texels of a texture (or of the background): the touched rows are packed again
+  for (size_t t = 0; t < d->tex_sources.size(); t++) {
+    const Image *img = d->tex_sources[t];
+    const RT_DTexture &desc = d->tex_descs[t];
+    if (img->width != desc.width || img->height != desc.height || img->components < 3 || img->pixel_type != PT_u8) continue;
+    const size_t row_bytes = (size_t)img->stride * img->components;
+    if (!range_in(begin, bytes, img->pixels.data, row_bytes * img->height, &off)) continue;
+    const size_t r0 = off / row_bytes, r1 = (off + bytes + row_bytes - 1) / row_bytes;
+    DevBuf stage;
+    HIP_TRY(stage.alloc((r1 - r0) * row_bytes));
+    HIP_TRY(hipMemcpy(stage.p, (const unsigned char *)img->pixels.data + r0 * row_bytes, (r1 - r0) * row_bytes, hipMemcpyHostToDevice));
+    int rc = rt_launch_pack_texture(stage.as<uint8_t>(), (int)img->width, (int)(r1 - r0), (int)img->stride, (int)img->components,
+                                    d->texels + desc.offset + r0 * (size_t)desc.width, nullptr);
+    if (rc == 0) rc = (int)hipDeviceSynchronize();
+    if (rc != 0) return rt_fail("rt_scene_touch: texture rows: %s", hipGetErrorString((hipError_t)rc));
+    return 1;
+  }
+  return 0;
+}
+
+static std::unordered_map<const Scene *, uint64_t> g_full_fp;     // full fingerprint at upload / after a touch; guarded by g_fp_mutex
+static std::mutex g_fp_mutex;
+// 0 = every resident copy was patched in place, 1 = copies were dropped (the next frame uploads), -1 = error
+extern "C" int rt_scene_touch(Scene const *scene, void const *begin, size_t bytes) {
+  if (!scene || !begin || bytes == 0) return rt_fail("rt_scene_touch: NULL scene or empty range");
+  int dropped = 0, patched = 0;
+  for (int i = 0; i < RT_MAX_DEVICES; i++) {
+    Device &D = g_devs[i];
+    std::lock_guard<std::mutex> lock(D.mutex);
+    auto it = D.scene_cache.find(scene);
+    if (it == D.scene_cache.end()) continue;
+    DeviceGuard guard(D);
+    RT_Device_Scene *d = it->second;
+    int rc = touch_device_scene(d, scene, begin, (size_t)bytes);
+    if (rc == 1) {
+      d->stamp = scene_stamp(scene, d->mat_ptrs, d->mat_first_tri);
+      patched += 1;
+    } else {
+      free_device_scene(d);
+      D.scene_cache.erase(it);
+      dropped += 1;
+      if (rc < 0) return -1;
+    }
+  }
+  if (patched) {
+    const uint64_t fp = scene_fingerprint(scene);
+    std::lock_guard<std::mutex> lock(g_fp_mutex);
+    g_full_fp[scene] = fp;
+  }
+  return dropped ? 1 : 0;
+}
+
 // Full content check of the cached device copy of `scene` on the primary device: 1 = the host scene still equals what was
 // uploaded (geometry and material bytes in full, texels of large images sampled), 0 = it changed (the copy is dropped,
 // the next frame uploads again), -1 = no cached copy.  The per-frame check is scene_stamp() above.
-static std::unordered_map<const Scene *, uint64_t> g_full_fp;     // guarded by dev0().mutex
+static bool fingerprint_matches(Scene const *scene) {
+  const uint64_t now = scene_fingerprint(scene);
+  std::lock_guard<std::mutex> lock(g_fp_mutex);
+  auto fp = g_full_fp.find(scene);
+  return fp != g_full_fp.end() && fp->second == now;
+}
 extern "C" int rt_scene_verify(Scene const *scene) {
   Device &D = dev0();
   std::lock_guard<std::mutex> lock(D.mutex);
   auto it = D.scene_cache.find(scene);
   if (it == D.scene_cache.end() || !scene) return -1;
-  auto fp = g_full_fp.find(scene);
-  if (fp != g_full_fp.end() && fp->second == scene_fingerprint(scene)) return 1;
+  if (fingerprint_matches(scene)) return 1;
   DeviceGuard guard(D);
   free_device_scene(it->second);
   D.scene_cache.erase(it);
-  g_full_fp.erase(scene);
   return 0;
 }
 
@@ -884,7 +1074,11 @@ static RT_Device_Scene *cached_scene_locked(Device &D, Scene const *scene, float
   RT_Device_Scene *d = upload_scene_locked(D, scene);
   if (d) {
     D.scene_cache[scene] = d;
-    if (D.slot == 0) g_full_fp[scene] = scene_fingerprint(scene);
+    if (D.slot == 0) {
+      const uint64_t fp = scene_fingerprint(scene);
+      std::lock_guard<std::mutex> lock(g_fp_mutex);
+      g_full_fp[scene] = fp;
+    }
   }
   if (upload_ms) *upload_ms = (float)(now_ms() - t1);
   return d;
@@ -938,17 +1132,73 @@ struct Partition {
 static std::vector<Partition *> g_partitions;
 static std::mutex               g_partition_mutex;   // the host tables and every Device::parts
 
+// The device copies of an evicted partition are not freed at once: device_chunk_list() / device_owner_table() hand out the
+// pointers and release g_partition_mutex before the kernel that reads them is enqueued (under the device's own mutex), and
+// another thread's 17th distinct (width, height, world) may evict in between.  They are RETIRED and freed by the eviction
+// after the next one -- every frame synchronises before it returns, so whatever read them has long finished by then.
+struct RetiredBuffer { int phys; void *ptr; };
+static std::vector<RetiredBuffer> g_retired[2];                 // [0]: retired by the latest eviction, [1]: by the one before
 static void drop_device_partitions(const Partition *q) {        // g_partition_mutex held
+  for (const RetiredBuffer &rb : g_retired[1]) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != rb.phys) (void)hipSetDevice(rb.phys);
+    (void)hipFree(rb.ptr);
+    if (prev >= 0 && prev != rb.phys) (void)hipSetDevice(prev);
+  }
+  g_retired[1].swap(g_retired[0]);
+  g_retired[0].clear();
   for (int i = 0; i < RT_MAX_DEVICES; i++) {
     Device &D = g_devs[i];
     for (size_t k = 0; k < D.parts.size(); k++) {
       if (D.parts[k].host != q) continue;
-      DeviceGuard guard(D);
-      for (int32_t *ptr : D.parts[k].d_lists) (void)hipFree(ptr);
-      (void)hipFree(D.parts[k].d_owner_slot);
+      for (int32_t *ptr : D.parts[k].d_lists) if (ptr) g_retired[0].push_back({D.phys, ptr});
+      if (D.parts[k].d_owner_slot) g_retired[0].push_back({D.phys, D.parts[k].d_owner_slot});
       D.parts.erase(D.parts.begin() + (long)k);
       break;
     }
+  }
+}
+
+// After rt_set_devices(): slot r >= 1 belongs to GPU (primary + r) mod count, or to the primary GPU when rehearsing.  A slot
+// that was initialised under the other mapping gives back what it holds on the old GPU -- scene copies, frame buffers,
+// events, partition tables -- and is initialised again by its next frame.
+static void remap_device_slots() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return;
+  const Config c = config();
+  for (int r = 1; r < RT_MAX_DEVICES; r++) {
+    Device &D = g_devs[r];
+    std::lock_guard<std::mutex> lock(D.mutex);
+    if (!D.ready) continue;
+    const int want = c.rehearse ? g_primary : (g_primary + r) % count;
+    if (want == D.phys) continue;
+    {
+      DeviceGuard guard(D);
+      (void)hipDeviceSynchronize();
+      for (auto &kv : D.scene_cache) free_device_scene(kv.second);
+      D.scene_cache.clear();
+      D.cameras.clear();
+      Workspace &W = D.ws;
+      (void)hipFree(W.accum); (void)hipFree(W.image); (void)hipFree(W.linear); (void)hipFree(W.tiles); (void)hipFree(W.all_tiles);
+      if (W.tiles_host) (void)hipHostFree(W.tiles_host);
+      if (W.counters_host) (void)hipHostFree(W.counters_host);
+      (void)hipFree(W.wave_times);
+      for (hipEvent_t e : W.ev0) (void)hipEventDestroy(e);
+      for (hipEvent_t e : W.ev1) (void)hipEventDestroy(e);
+      for (int i = 0; i < 5; i++) if (W.ev_frame[i]) (void)hipEventDestroy(W.ev_frame[i]);
+      W = Workspace();
+      D.last_counters = nullptr;
+    }
+    {
+      std::lock_guard<std::mutex> pl(g_partition_mutex);
+      for (DevPartition &dp : D.parts) {
+        for (int32_t *ptr : dp.d_lists) if (ptr) g_retired[0].push_back({D.phys, ptr});
+        if (dp.d_owner_slot) g_retired[0].push_back({D.phys, dp.d_owner_slot});
+      }
+      D.parts.clear();
+    }
+    D.ready = false;
   }
 }
 
@@ -1423,6 +1673,10 @@ extern "C" int rt_render_accumulate(RT_Device_Scene *dscene, RT_Render_Params co
   DeviceGuard guard(D);
   auto it = D.cameras.find(dscene);
   if (it == D.cameras.end()) return rt_fail("rt_render_accumulate: no camera set for this scene (rt_set_camera)");
+  {
+    std::lock_guard<std::mutex> lk(g_multi_mutex);           // rt_get_counters() now means THIS launch, not an older multi-device frame
+    g_multi_counters_valid = false;
+  }
   return render_accumulate_locked(D, dscene, &it->second, params, d_accum, (hipStream_t)stream);
 }
 
@@ -1543,66 +1797,240 @@ static float event_ms(hipEvent_t a, hipEvent_t b) {
 // pixels.  Devices are driven by one internal host thread each (uploads and launches proceed in parallel; the calling
 // application's other threads return at once, as in the one-GPU case).  Per-path seeds depend on (pixel, sample) only, so
 // the image does not depend on N (tests/test_gpu_multi_device.py: byte-equal to the one-device frame).
+// How the N devices are driven (round 4):
+//  * one PERSISTENT internal host thread per device slot >= 1, started the first time the slot is used and parked on a
+//    condition variable between frames (round 3 created and joined N - 1 threads per frame);
+//  * a device thread only ENQUEUES -- clear, preparation, path kernel, resolve to compact tiles, the tile copy towards slot 0,
+//    an asynchronous copy of its ray counters into pinned host memory, an event -- and returns; nothing on it waits for the GPU;
+//  * slot 0's stream waits for the other devices' events (hipStreamWaitEvent), untiles, copies the image out: ONE host
+//    synchronisation per frame, at the end;
+//  * a device without peer access to slot 0 (hipDeviceCanAccessPeer refused) stages its tiles through pinned host memory;
+//  * the full content check of the host scene (rt_scene_touch) runs on the calling thread while all of that is in flight;
+//  * rt_get_frame_timing() reports the slowest device's prep / path / resolve / copy times, the gather + untile + copy-out
+//    time after it, and which device it was.
+struct MultiFrame {
+  Scene const      *scene = nullptr;
+  RT_Render_Params  base;
+  int               world = 0, w = 0, h = 0;
+  size_t            tiles_bytes = 0;
+  int               rcs[RT_MAX_DEVICES];
+  bool              staged[RT_MAX_DEVICES];
+  float             stamp_ms[RT_MAX_DEVICES], upload_ms[RT_MAX_DEVICES], enqueue_ms[RT_MAX_DEVICES];
+  char              err[RT_MAX_DEVICES][256];
+  std::mutex              m;
+  std::condition_variable cv;
+  int                     pending = 0;
+};
+
+struct DevWorker {
+  std::mutex              m;
+  std::condition_variable cv;
+  MultiFrame             *job = nullptr;
+  bool                    started = false;
+};
+static DevWorker *g_workers = new DevWorker[RT_MAX_DEVICES];     // never destroyed: the parked threads outlive static destructors
+
+#ifdef RT_DIAG_VARIANTS
+// fault injection for tests/test_gpu_multi_device.py (diagnostic library only): bit 0 = pretend no device has peer access
+// to slot 0 (staged tile copies), bits 8.. = 1 + the slot whose frame fails
+static std::atomic<int> g_multi_fault{0};
+extern "C" void rt_diag_multi_fault(i32 no_peer, i32 failing_slot) {
+  g_multi_fault.store((no_peer ? 1 : 0) | ((failing_slot >= 0 ? failing_slot + 1 : 0) << 8));
+}
+static bool fault_no_peer() { return (g_multi_fault.load() & 1) != 0; }
+static bool fault_fails(int slot) { return (g_multi_fault.load() >> 8) == slot + 1; }
+#else
+static inline bool fault_no_peer() { return false; }
+static inline bool fault_fails(int) { return false; }
+#endif
+
+static void device_fail(MultiFrame &J, int r, const char *what) {
+  Device &D = g_devs[r];
+  snprintf(J.err[r], sizeof J.err[r], "device %d (slot %d of %d): %s", D.phys, r, J.world, what);
+}
+
+// Everything device slot `r` contributes to the frame, enqueued on its null stream; returns without waiting for the GPU.
+static void enqueue_device_frame(MultiFrame &J, int r) {
+  Device &D = g_devs[r];
+  Device &D0 = dev0();
+  std::unique_lock<std::mutex> lock(D.mutex, std::defer_lock);
+  if (r != 0) lock.lock();                                   // (slot 0's mutex is held by the frame's owner)
+  J.rcs[r] = -1;
+  J.staged[r] = false;
+  J.err[r][0] = 0;
+  D.slot = r;
+  if (ensure_device(D) != 0) { device_fail(J, r, rt_last_error()); return; }       // assigns D.phys and makes it this thread's device
+  if (fault_fails(r)) { device_fail(J, r, "injected failure (rt_diag_multi_fault)"); return; }
+  RT_Device_Scene *d = cached_scene_locked(D, J.scene, &J.stamp_ms[r], &J.upload_ms[r]);
+  if (!d) { device_fail(J, r, rt_last_error()); return; }
+  const double t_enq = now_ms();
+  Workspace &W = D.ws;
+  if (ensure_frame_buffers(D, J.w, J.h, J.tiles_bytes, r == 0 ? J.tiles_bytes * (size_t)J.world : 0) != 0) { device_fail(J, r, rt_last_error()); return; }
+  if (!W.counters_host && hipHostMalloc((void **)&W.counters_host, RT_N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+    device_fail(J, r, "pinned counter buffer"); return;
+  }
+  const bool same_gpu = D.phys == D0.phys;
+  const bool direct = same_gpu || (D.peer_ok && !fault_no_peer());
+  if (!direct && W.tiles_host_bytes < J.tiles_bytes) {
+    if (W.tiles_host) (void)hipHostFree(W.tiles_host);
+    W.tiles_host = nullptr; W.tiles_host_bytes = 0;
+    if (hipHostMalloc((void **)&W.tiles_host, J.tiles_bytes, hipHostMallocDefault) != hipSuccess) { device_fail(J, r, "pinned tile buffer"); return; }
+    W.tiles_host_bytes = J.tiles_bytes;
+  }
+  RT_Render_Params p = J.base;
+  p.rank = r;
+  p.world = J.world;
+  hipStream_t stream = nullptr;
+  hipError_t e = hipEventRecord(W.ev_frame[0], stream);
+  if (e == hipSuccess) e = hipMemsetAsync(W.accum, 0, (size_t)J.w * J.h * 3 * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) { device_fail(J, r, hipGetErrorString(e)); return; }
+  if (render_accumulate_locked(D, d, &J.scene->camera, &p, W.accum, stream, W.ev_frame[1]) != 0) { device_fail(J, r, rt_last_error()); return; }
+  (void)hipEventRecord(W.ev_frame[2], stream);
+  if (resolve_on(D, &p, W.accum, W.tiles, nullptr, nullptr, stream) != 0) { device_fail(J, r, rt_last_error()); return; }
+  (void)hipEventRecord(W.ev_frame[3], stream);
+  uint8_t *dst = D0.ws.all_tiles + (size_t)r * J.tiles_bytes;
+  if (same_gpu) e = hipMemcpyAsync(dst, W.tiles, J.tiles_bytes, hipMemcpyDeviceToDevice, stream);
+  else if (direct) e = hipMemcpyPeerAsync(dst, D0.phys, W.tiles, D.phys, J.tiles_bytes, stream);      // one xGMI link per device
+  else { e = hipMemcpyAsync(W.tiles_host, W.tiles, J.tiles_bytes, hipMemcpyDeviceToHost, stream); J.staged[r] = true; }
+  if (e == hipSuccess) e = hipMemcpyAsync(W.counters_host, d->counters, RT_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipEventRecord(W.ev_frame[4], stream);
+  if (e != hipSuccess) { device_fail(J, r, hipGetErrorString(e)); return; }
+  J.enqueue_ms[r] = (float)(now_ms() - t_enq);
+  J.rcs[r] = 0;
+}
+
+static void worker_loop(int r) {
+  DevWorker &Wk = g_workers[r];
+  for (;;) {
+    MultiFrame *J;
+    {
+      std::unique_lock<std::mutex> lk(Wk.m);
+      Wk.cv.wait(lk, [&] { return Wk.job != nullptr; });
+      J = Wk.job;
+      Wk.job = nullptr;
+    }
+    enqueue_device_frame(*J, r);
+    {
+      std::lock_guard<std::mutex> lk(J->m);
+      J->pending -= 1;
+    }
+    J->cv.notify_all();
+  }
+}
+
+static void drop_scene_everywhere_but0(Scene const *scene, int world) {
+  for (int r = 1; r < world; r++) {
+    Device &D = g_devs[r];
+    std::lock_guard<std::mutex> lock(D.mutex);
+    auto it = D.scene_cache.find(scene);
+    if (it == D.scene_cache.end()) continue;
+    DeviceGuard guard(D);
+    (void)hipDeviceSynchronize();
+    free_device_scene(it->second);
+    D.scene_cache.erase(it);
+  }
+}
+
 static int render_frame_multi(Scene const *scene, Image const *image, RT_Render_Params base, int world) {
   Device &D0 = dev0();                               // D0.mutex held by the caller
+  const double t0 = now_ms();
   const int w = base.width, h = base.height;
   const size_t max_local = (size_t)rt_max_local_chunk_count(w, h, world);
   const size_t tiles_bytes = max_local * 1024 * 3;
   if (ensure_frame_buffers(D0, w, h, tiles_bytes, tiles_bytes * (size_t)world) != 0) return -1;
-  const double t0 = now_ms();
-  std::vector<int> rcs((size_t)world, 0);
-  std::vector<RT_Counters> cnts((size_t)world);
-  auto work = [&](int r) {
-    Device &D = g_devs[r];
-    std::unique_lock<std::mutex> lock(D.mutex, std::defer_lock);
-    if (r != 0) lock.lock();
-    D.slot = r;
-    DeviceGuard guard(D);
-    rcs[(size_t)r] = -1;
-    if (ensure_device(D) != 0) return;
-    RT_Device_Scene *d = cached_scene_locked(D, scene, nullptr, nullptr);
-    if (!d) return;
-    if (ensure_frame_buffers(D, w, h, tiles_bytes, r == 0 ? tiles_bytes * (size_t)world : 0) != 0) return;
-    RT_Render_Params p = base;
-    p.rank = r;
-    p.world = world;
-    hipStream_t stream = nullptr;
-    if (hipMemsetAsync(D.ws.accum, 0, (size_t)w * h * 3 * sizeof(unsigned long long), stream) != hipSuccess) { rt_fail("hipMemsetAsync failed"); return; }
-    if (render_accumulate_locked(D, d, &scene->camera, &p, D.ws.accum, stream) != 0) return;
-    if (resolve_on(D, &p, D.ws.accum, D.ws.tiles, nullptr, nullptr, stream) != 0) return;
-    uint8_t *dst = D0.ws.all_tiles + (size_t)r * tiles_bytes;
-    hipError_t e = (D.phys == D0.phys) ? hipMemcpyAsync(dst, D.ws.tiles, tiles_bytes, hipMemcpyDeviceToDevice, stream)
-                                       : hipMemcpyPeerAsync(dst, D0.phys, D.ws.tiles, D.phys, tiles_bytes, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) { rt_fail("tile copy from device %d failed: %s", D.phys, hipGetErrorString(e)); return; }
-    unsigned long long c[RT_N_COUNTERS];
-    if (hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { rt_fail("counter read-back failed"); return; }
-    RT_Counters &o = cnts[(size_t)r];
-    o.paths = c[0]; o.rays = c[1]; o.node_visits = c[2]; o.leaf_visits = c[3]; o.shades = c[4]; o.backgrounds = c[5]; o.textured = c[6];
-    rcs[(size_t)r] = 0;
-  };
-  std::vector<std::thread> helpers;
-  for (int r = 1; r < world; r++) helpers.emplace_back(work, r);
-  work(0);
-  for (auto &t : helpers) t.join();
-  for (int r = 0; r < world; r++)
-    if (rcs[(size_t)r] != 0) return -1;
+  const bool verify = !scene_is_static(scene);
+  FrameTiming T;
+  T.n_devices = world;
+  static MultiFrame J;                               // (one multi-device frame at a time: D0.mutex)
+  for (int attempt = 0;; attempt++) {
+    J.scene = scene; J.base = base; J.world = world; J.w = w; J.h = h; J.tiles_bytes = tiles_bytes;
+    for (int r = 0; r < world; r++) { J.stamp_ms[r] = J.upload_ms[r] = J.enqueue_ms[r] = 0.0f; J.rcs[r] = -1; }
+    {
+      std::lock_guard<std::mutex> lk(J.m);
+      J.pending = world - 1;
+    }
+    for (int r = 1; r < world; r++) {
+      DevWorker &Wk = g_workers[r];
+      {
+        std::lock_guard<std::mutex> lk(Wk.m);
+        if (!Wk.started) { std::thread(worker_loop, r).detach(); Wk.started = true; }
+        Wk.job = &J;
+      }
+      Wk.cv.notify_one();
+    }
+    enqueue_device_frame(J, 0);
+    // the full content check of the host scene while every device renders (see rt_scene_touch)
+    bool stale = false;
+    if (verify && attempt == 0) {
+      const double t_v = now_ms();
+      stale = !fingerprint_matches(scene);
+      T.verify_ms = (float)(now_ms() - t_v);
+    }
+    {
+      std::unique_lock<std::mutex> lk(J.m);
+      J.cv.wait(lk, [&] { return J.pending == 0; });
+    }
+    int failed = -1;
+    for (int r = 0; r < world; r++)
+      if (J.rcs[r] != 0 && failed < 0) failed = r;
+    if (J.upload_ms[0] > 0.0f) stale = false;          // (slot 0 uploaded in this very frame: the fingerprint is that upload's)
+    if (failed >= 0 || stale) {
+      // nothing may still be writing into slot 0's tile buffer, or reading a scene copy, when we leave or start over
+      for (int r = 0; r < world; r++)
+        if (J.rcs[r] == 0) (void)hipEventSynchronize(g_devs[r].ws.ev_frame[4]);
+      if (failed >= 0) return rt_fail("multi-device frame failed: %s", J.err[failed][0] ? J.err[failed] : "unknown error");
+      auto it = D0.scene_cache.find(scene);
+      if (it != D0.scene_cache.end()) { free_device_scene(it->second); D0.scene_cache.erase(it); }
+      drop_scene_everywhere_but0(scene, world);
+      continue;                                       // the host scene changed under the cached copies: upload and render again
+    }
+    break;
+  }
   DeviceGuard guard(D0);
-  if (untile_on(D0, w, h, world, D0.ws.all_tiles, D0.ws.image, nullptr) != 0) return -1;
-  if (copy_image_out(image, D0.ws.image, w, h, nullptr) != 0) return -1;
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  hipStream_t s0 = nullptr;
+  const double t_g = now_ms();
+  for (int r = 1; r < world; r++) {
+    Workspace &W = g_devs[r].ws;
+    if (J.staged[r]) {                                // no peer access: pinned host memory -> slot 0
+      HIP_TRY(hipEventSynchronize(W.ev_frame[4]));
+      HIP_TRY(hipMemcpyAsync(D0.ws.all_tiles + (size_t)r * tiles_bytes, W.tiles_host, tiles_bytes, hipMemcpyHostToDevice, s0));
+    } else {
+      HIP_TRY(hipStreamWaitEvent(s0, W.ev_frame[4], 0));
+    }
+  }
+  if (untile_on(D0, w, h, world, D0.ws.all_tiles, D0.ws.image, s0) != 0) return -1;
+  if (copy_image_out(image, D0.ws.image, w, h, s0) != 0) return -1;
+  HIP_TRY(hipStreamSynchronize(s0));
+  // the slowest device's split, the ray counters of all
+  float worst = -1.0f;
+  RT_Counters sum;
+  memset(&sum, 0, sizeof sum);
+  for (int r = 0; r < world; r++) {
+    Workspace &W = g_devs[r].ws;
+    const float span = event_ms(W.ev_frame[0], W.ev_frame[4]);
+    if (span > worst) {
+      worst = span;
+      T.slowest_device = r;
+      T.gpu_prep_ms = event_ms(W.ev_frame[0], W.ev_frame[1]);
+      T.gpu_path_ms = event_ms(W.ev_frame[1], W.ev_frame[2]);
+      T.gpu_resolve_ms = event_ms(W.ev_frame[2], W.ev_frame[3]);
+      T.gpu_copy_ms = event_ms(W.ev_frame[3], W.ev_frame[4]);         // its tiles to slot 0 (+ counters)
+    }
+    T.stamp_ms = J.stamp_ms[r] > T.stamp_ms ? J.stamp_ms[r] : T.stamp_ms;
+    T.upload_ms = J.upload_ms[r] > T.upload_ms ? J.upload_ms[r] : T.upload_ms;
+    T.enqueue_ms = J.enqueue_ms[r] > T.enqueue_ms ? J.enqueue_ms[r] : T.enqueue_ms;
+    const unsigned long long *c = W.counters_host;
+    sum.paths += c[0]; sum.rays += c[1]; sum.node_visits += c[2]; sum.leaf_visits += c[3]; sum.shades += c[4]; sum.backgrounds += c[5];
+    sum.textured += c[6];
+  }
+  T.gather_ms = (float)(now_ms() - t_g);
   {
     std::lock_guard<std::mutex> lk(g_multi_mutex);
-    memset(&g_multi_counters, 0, sizeof g_multi_counters);
-    for (const RT_Counters &o : cnts) {
-      g_multi_counters.paths += o.paths; g_multi_counters.rays += o.rays; g_multi_counters.node_visits += o.node_visits;
-      g_multi_counters.leaf_visits += o.leaf_visits; g_multi_counters.shades += o.shades; g_multi_counters.backgrounds += o.backgrounds;
-      g_multi_counters.textured += o.textured;
-    }
+    g_multi_counters = sum;
     g_multi_counters_valid = true;
   }
-  D0.timing = FrameTiming();
-  D0.timing.total_ms = (float)(now_ms() - t0);
+  T.total_ms = (float)(now_ms() - t0);
+  D0.timing = T;
   return 0;
 }
 
@@ -1633,21 +2061,36 @@ static int render_frame_locked(Scene const *scene, Image const *image, isize sam
     return render_frame_multi(scene, image, p, world);
 
   FrameTiming T;
-  RT_Device_Scene *d = cached_scene_locked(D, scene, &T.stamp_ms, &T.upload_ms);
-  if (!d) return -1;
   if (ensure_frame_buffers(D, p.width, p.height, 0, 0) != 0) return -1;
   Workspace &W = D.ws;
-
   size_t pixels = (size_t)p.width * p.height;
   hipStream_t stream = nullptr;
-  const double t_enq = now_ms();
-  HIP_TRY(hipEventRecord(W.ev_frame[0], stream));
-  HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 3 * sizeof(unsigned long long), stream));
-  if (render_accumulate_locked(D, d, &scene->camera, &p, W.accum, stream, W.ev_frame[1]) != 0) return -1;
-  HIP_TRY(hipEventRecord(W.ev_frame[2], stream));
-  if (resolve_on(D, &p, W.accum, nullptr, W.image, linear ? W.linear : nullptr, stream) != 0) return -1;
-  HIP_TRY(hipEventRecord(W.ev_frame[3], stream));
-  T.enqueue_ms = (float)(now_ms() - t_enq);
+  const bool verify = !scene_is_static(scene);
+  for (int attempt = 0;; attempt++) {
+    float stamp_ms = 0.0f, upload_ms = 0.0f;
+    RT_Device_Scene *d = cached_scene_locked(D, scene, &stamp_ms, &upload_ms);
+    if (!d) return -1;
+    T.stamp_ms += stamp_ms;
+    T.upload_ms += upload_ms;
+    const double t_enq = now_ms();
+    HIP_TRY(hipEventRecord(W.ev_frame[0], stream));
+    HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 3 * sizeof(unsigned long long), stream));
+    if (render_accumulate_locked(D, d, &scene->camera, &p, W.accum, stream, W.ev_frame[1]) != 0) return -1;
+    HIP_TRY(hipEventRecord(W.ev_frame[2], stream));
+    if (resolve_on(D, &p, W.accum, nullptr, W.image, linear ? W.linear : nullptr, stream) != 0) return -1;
+    HIP_TRY(hipEventRecord(W.ev_frame[3], stream));
+    T.enqueue_ms = (float)(now_ms() - t_enq);
+    // the full content check of the host scene, on this thread, while the GPU renders (see rt_scene_touch): a frame of an
+    // unchanged scene waits for max(kernel, check) instead of kernel + check; a changed scene is uploaded and rendered again
+    if (!verify || attempt > 0 || upload_ms > 0.0f) break;
+    const double t_v = now_ms();
+    const bool same = fingerprint_matches(scene);
+    T.verify_ms = (float)(now_ms() - t_v);
+    if (same) break;
+    HIP_TRY(hipStreamSynchronize(stream));
+    free_device_scene(d);
+    D.scene_cache.erase(scene);
+  }
 
   if (copy_image_out(image, W.image, p.width, p.height, stream) != 0) return -1;
   HIP_TRY(hipEventRecord(W.ev_frame[4], stream));
@@ -1682,6 +2125,8 @@ extern "C" int rt_get_frame_timing(RT_Frame_Timing *out) {
   out->stamp_ms = D.timing.stamp_ms; out->upload_ms = D.timing.upload_ms; out->enqueue_ms = D.timing.enqueue_ms;
   out->gpu_prep_ms = D.timing.gpu_prep_ms; out->gpu_path_ms = D.timing.gpu_path_ms; out->gpu_resolve_ms = D.timing.gpu_resolve_ms;
   out->gpu_copy_ms = D.timing.gpu_copy_ms; out->total_ms = D.timing.total_ms;
+  out->verify_ms = D.timing.verify_ms; out->gather_ms = D.timing.gather_ms;
+  out->n_devices = D.timing.n_devices; out->slowest_device = D.timing.slowest_device;
   return 0;
 }
 
@@ -1857,6 +2302,10 @@ static int lightmap_bake_locked(Device &D, Image const *lightmap, Scene const *s
 extern "C" void lightmap_bake(Image const *lightmap, Scene const *scene, isize samples) {
   Device &D = dev0();
   std::lock_guard<std::mutex> lock(D.mutex);
+  {
+    std::lock_guard<std::mutex> lk(g_multi_mutex);
+    g_multi_counters_valid = false;
+  }
   lightmap_bake_locked(D, lightmap, scene, samples);
 }
 

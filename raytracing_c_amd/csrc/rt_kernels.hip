@@ -816,7 +816,9 @@ __global__ __launch_bounds__(1024) void rt_prepare_kernel(int n_tiles, uint32_t 
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int i = group + 64 * k + lane;
-      bk[k] = i < last ? (int)cost_prev[i] : -1;
+      // (an unsigned cost of 2^31 or more must not read as "no tile" -- the tile would drop out of the count AND of the scatter and
+      //  leave a stale entry in the order: it saturates; the bucket function is monotonic)
+      bk[k] = i < last ? (int)(cost_prev[i] > 0x7FFFFFFFu ? 0x7FFFFFFFu : cost_prev[i]) : -1;
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -851,7 +853,9 @@ __global__ __launch_bounds__(1024) void rt_prepare_kernel(int n_tiles, uint32_t 
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int i = group + 64 * k + lane;
-      bk[k] = i < last ? (int)cost_prev[i] : -1;
+      // (an unsigned cost of 2^31 or more must not read as "no tile" -- the tile would drop out of the count AND of the scatter and
+      //  leave a stale entry in the order: it saturates; the bucket function is monotonic)
+      bk[k] = i < last ? (int)(cost_prev[i] > 0x7FFFFFFFu ? 0x7FFFFFFFu : cost_prev[i]) : -1;
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {

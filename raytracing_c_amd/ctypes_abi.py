@@ -122,7 +122,8 @@ class RT_Counters(C.Structure):  # rt_hip.h
 
 class RT_Frame_Timing(C.Structure):  # rt_hip.h
     _fields_ = [(n, C.c_float) for n in
-                ("stamp_ms", "upload_ms", "enqueue_ms", "gpu_prep_ms", "gpu_path_ms", "gpu_resolve_ms", "gpu_copy_ms", "total_ms")]
+                ("stamp_ms", "upload_ms", "enqueue_ms", "gpu_prep_ms", "gpu_path_ms", "gpu_resolve_ms", "gpu_copy_ms", "total_ms",
+                 "verify_ms", "gather_ms")] + [("n_devices", C.c_int32), ("slowest_device", C.c_int32)]
 
 
 class RT_Render_Params(C.Structure):  # rt_hip.h
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = [
     # rt_hip.h
     "rt_last_error", "rt_clear_error", "rt_init", "rt_set_seed", "rt_get_seed",
     "rt_set_devices", "rt_device_count", "rt_math_contract",
-    "rt_scene_verify", "rt_get_frame_timing",
+    "rt_scene_verify", "rt_scene_touch", "rt_scene_set_static", "rt_get_frame_timing",
     "rt_scene_upload", "rt_scene_release", "rt_scene_invalidate", "rt_scene_device_bytes", "rt_set_camera",
     "rt_chunk_count", "rt_chunk_owner", "rt_local_chunk_count", "rt_max_local_chunk_count", "rt_local_chunk_list", "rt_render_accumulate", "rt_resolve", "rt_untile",
     "rt_denoise", "rt_render_frame", "rt_get_counters", "rt_last_kernel_ms", "rt_kernel_timing_reset", "rt_kernel_timing_mean_ms",
@@ -163,7 +164,7 @@ EXPORTED_SYMBOLS = [
 # include/rt_hip_diag.h: exported by librt_hip_diag.so only (which also exports everything above); the product library must
 # NOT carry them (tests/test_abi.py)
 DIAG_ONLY_SYMBOLS = [
-    "rt_diag_set_tokens", "rt_set_pipeline", "rt_get_pipeline", "rt_set_wavefront_capacity", "rt_get_sched_stats", "rt_get_wave_times", "rt_get_ledger",
+    "rt_diag_set_tokens", "rt_diag_multi_fault", "rt_set_pipeline", "rt_get_pipeline", "rt_set_wavefront_capacity", "rt_get_sched_stats", "rt_get_wave_times", "rt_get_ledger",
     "rt_test_math", "rt_test_rcp_sweep", "rt_test_srgb_sweep", "rt_test_quantize_sweep", "rt_test_trace", "rt_test_trace_stream",
     "rt_test_tile_order", "rt_test_texture",
 ]

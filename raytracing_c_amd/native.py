@@ -132,6 +132,9 @@ def _declare(d):
     d.rt_set_devices.argtypes = [C.c_int32, C.c_int32]
     d.rt_device_count.restype = C.c_int32
     d.rt_scene_verify.argtypes = [P(abi.Scene)]
+    d.rt_scene_touch.argtypes = [P(abi.Scene), vp, C.c_size_t]
+    d.rt_scene_set_static.argtypes = [P(abi.Scene), C.c_int32]
+    d.rt_scene_set_static.restype = None
     d.rt_get_frame_timing.argtypes = [P(abi.RT_Frame_Timing)]
     d.render_thread_proc.argtypes = [P(abi.Rendering_Context)]
     d.render_thread_proc.restype = None
@@ -165,6 +168,8 @@ def _declare_diag(d):
     d.rt_get_sched_stats.argtypes = [vp]
     d.rt_get_wave_times.argtypes = [vp, C.c_int32]
     d.rt_get_ledger.argtypes = [vp, C.c_int32]
+    d.rt_diag_multi_fault.argtypes = [C.c_int32, C.c_int32]
+    d.rt_diag_multi_fault.restype = None
     d.rt_diag_set_tokens.argtypes = [vp, vp, vp]
     d.rt_diag_set_tokens.restype = None
 

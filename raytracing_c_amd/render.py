@@ -60,12 +60,12 @@ def render_frame(hs: HostScene, width, height, samples, max_bounces, seed=0x1234
     return dict(image=out, linear=linear, accum=accum, counters=get_counters(lib))
 
 
-def render_context(hs: HostScene, width, height, samples, max_bounces, n_threads=1, seed=0x1234ABCD):
+def render_context(hs: HostScene, width, height, samples, max_bounces, n_threads=1, seed=0x1234ABCD, lib=None, fill=0):
     """The reference driver's protocol (driver.c:793-818): n_threads threads enter
     render_thread_proc on one Rendering_Context, the caller polls is_finished."""
-    lib = _lib
+    lib = lib or _lib
     lib.rt_set_seed(seed)
-    out = np.zeros((height, width, 3), np.uint8)
+    out = np.full((height, width, 3), fill, np.uint8)
     ctx = abi.Rendering_Context()
     ctx.image.components = 3
     ctx.image.pixel_type = 0

@@ -116,7 +116,8 @@ def _textured_quad():
 def test_in_place_scene_edits_are_seen_by_the_next_frame(rt, oracle):
     """The reference reads the live Scene every frame (raytracer.c:596-720 holds no copy).  render_thread_proc keeps a
     device copy per Scene*, so it must notice host-side edits: a material colour, a vertex, a texture swapped for
-    another Image are all covered by the content stamp; a single edited texel needs rt_scene_invalidate()."""
+    another Image, a single texel: all seen by the next frame without any call (the stamp before the frame, the full content
+    check while the GPU renders it)."""
     from tests import _oracle
     hs = _textured_quad()
     w, h, s, b = 48, 32, 4, 3
@@ -138,10 +139,101 @@ def test_in_place_scene_edits_are_seen_by_the_next_frame(rt, oracle):
     assert np.array_equal(got3, _oracle.render(hs, w, h, s, b)["image"])
     assert not np.array_equal(got3, got2)
 
-    hs._image_arrays[0][1, 2, 0] ^= 0x80                    # 4. ONE texel: outside the stamp's sample -> explicit invalidate
-    rt.lib.rt_scene_invalidate(C.byref(hs.scene))
+    hs._image_arrays[0][1, 2, 0] ^= 0x80                    # 4. ONE texel of a small image (hashed in full): seen
     got4 = rt.render_context(hs, w, h, s, b)["image"]
     assert np.array_equal(got4, _oracle.render(hs, w, h, s, b)["image"])
+    assert not np.array_equal(got4, got3)
+
+
+def _big_textured_quad(size=2048):
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.scene import Material, build_scene
+    pos = np.array([[[-1, -1, 0], [1, -1, 0], [1, 1, 0]], [[-1, -1, 0], [1, 1, 0], [-1, 1, 0]]], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (2, 3, 1))
+    uv = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32)
+    tex = np.random.default_rng(3).integers(40, 90, (size, size, 3), dtype=np.uint8)
+    cam = np.eye(4, dtype=np.float32)
+    cam[2, 3] = 2.2
+    mats = [Material(base_color=(1.0, 1.0, 1.0), roughness=0.9, texture_albedo=0)]
+    return build_scene(pos, nrm, uv, np.zeros(2, np.int32), mats, [tex], cam, 0.9, procedural_background(64, 32))
+
+
+def test_scene_touch_patches_one_texel_of_a_2048_texture_without_a_re_upload(rt, oracle):
+    """VERDICT r03 #9 / ADVICE r03: rt_scene_touch(scene, begin, bytes) -- "I wrote these bytes".  A SINGLE texel of a 12 MB
+    texture changes in place (the 1-in-61 sampling of the full check can miss it); after the call the next frame shows it,
+    equal to the oracle on the edited host scene, and nothing was uploaded again: the touched ROW was packed again."""
+    from raytracing_c_amd import ctypes_abi as abi
+    from tests import _oracle
+    hs = _big_textured_quad()
+    w, h, s, b = 64, 64, 64, 3
+    first = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(first["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    tex = hs._image_arrays[0]
+    # a block of texels would be easy to see; ONE texel needs a sample whose bilinear footprint contains it: pick one the oracle sees
+    for (ty, tx) in [(1024, 1024), (1031, 1017), (700, 1300), (1500, 900), (999, 1111), (1200, 800), (860, 1240), (1100, 1150)]:
+        old = tex[ty, tx].copy()
+        tex[ty, tx] = (255, 255, 255)
+        want = _oracle.render(hs, w, h, s, b)
+        if not np.array_equal(want["accum"], first["accum"]):
+            break
+        tex[ty, tx] = old
+    else:
+        pytest.fail("no candidate texel is sampled by this frame")
+    rc = rt.lib.rt_scene_touch(C.byref(hs.scene), tex[ty, tx:].ctypes.data, 3)
+    assert rc == 0, rt.last_error()
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(got["accum"], want["accum"])
+    t = abi.RT_Frame_Timing()
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0
+    assert t.upload_ms == 0.0, "the texture row was patched: no upload of the scene"
+    # the same through the reference's own entry point, and a vertex through rt_scene_touch
+    soa = hs.soa_array()
+    soa[6:9, :2] -= 0.125
+    assert rt.lib.rt_scene_touch(C.byref(hs.scene), soa[6:].ctypes.data, 3 * soa.shape[1] * 4) in (0, 1)
+    got2 = rt.render_context(hs, w, h, s, b)["image"]
+    assert np.array_equal(got2, _oracle.render(hs, w, h, s, b)["image"])
+    # a range that belongs to nothing the copy was made from: the copy is dropped, the next frame uploads
+    junk = np.zeros(16, np.uint8)
+    assert rt.lib.rt_scene_touch(C.byref(hs.scene), junk.ctypes.data, 16) == 1
+    got3 = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(got3["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0 and t.upload_ms > 0.0
+
+
+def test_in_place_vertex_edit_inside_a_large_block_is_seen_without_any_call(rt, oracle):
+    """ONE vertex in the middle of 4 800 triangles moves in place -- outside the bytes the microsecond
+    stamp samples.  The full content check runs on the calling thread while the GPU renders the frame; it throws the stale
+    frame away, uploads and renders again: the caller gets the frame of the scene as it is, like the reference's."""
+    from raytracing_c_amd import ctypes_abi as abi
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("spheres")
+    w, h, s, b = 64, 40, 4, 4
+    a = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(a["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    T = hs.scene.triangles
+    i = int(T.len) // 2 + 37
+    x0 = T.x[0][i]
+    T.x[0][i] = x0 + 0.25
+    want = _oracle.render(hs, w, h, s, b)
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(got["accum"], want["accum"])
+    t = abi.RT_Frame_Timing()
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0
+    assert t.upload_ms > 0.0 and t.verify_ms > 0.0            # (the check found the edit: the scene went up again)
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)    # unchanged now: checked again, nothing uploaded
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0
+    assert np.array_equal(got["accum"], want["accum"]) and t.upload_ms == 0.0 and t.verify_ms > 0.0
+    # a host that never edits in place opts out of the check (and tells the library when it does edit: rt_scene_touch)
+    rt.lib.rt_scene_set_static(C.byref(hs.scene), 1)
+    rt.render_frame(hs, w, h, s, b)
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0 and t.verify_ms == 0.0
+    T.x[0][i] = x0
+    assert rt.lib.rt_scene_touch(C.byref(hs.scene), C.addressof(T.x[0].contents) + 4 * i, 4) == 0
+    back = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(back["accum"], a["accum"])
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0 and t.upload_ms == 0.0
+    rt.lib.rt_scene_set_static(C.byref(hs.scene), 0)
 
 
 def test_scene_rebuilt_at_the_same_address_is_not_served_from_the_cache(rt, oracle):
