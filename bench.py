@@ -132,9 +132,12 @@ def launch_ranks(args):
 
 
 def cpu_baseline(hs, cfg, target_seconds):
-    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
-    the full 1920x1080 frame at reduced spp, all host cores.  Test infrastructure used as
-    the measured CPU baseline only -- never on the product path."""
+    """The CPU checker (oracle/oracle.c) as the measured CPU baseline, on a bounded sample of the same workload: the full
+    frame at (possibly) reduced spp.  kind "port-avx2": the reference's 8-wide AVX2 forms of ray_aabbs_hit_8 /
+    ray_triangles_hit_8 / min_f32x8 (raytracer.c:15-32,84-230) restated in the checker and proven bit-identical to its
+    scalar form (tests/test_oracle_simd.py) -- the reference's SIMD CPU path, which north_star asks to be timed on the same
+    box's host cores; the scalar form's figures stand beside it (`scalar`).  T = all host threads and T = 1.
+    Test infrastructure used as the measured baseline only -- never on the product path."""
     import subprocess
     import tempfile
     from tests import _oracle
@@ -166,29 +169,41 @@ def cpu_baseline(hs, cfg, target_seconds):
     try:
         tmp = tempfile.mkdtemp(prefix="oracle_native_")
         out = os.path.join(tmp, "liboracle_native.so")
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "MARCH=native", f"OUT={out}"],
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "MARCH=native", f"OUT={out}", out],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lib = _oracle.load(out)
     except Exception:
         lib = _oracle.load()
     w, h, b = cfg["width"], cfg["height"], cfg["max_bounces"]
-    t0 = time.perf_counter()
-    r = _oracle.render(hs, w, h, 1, b, n_threads=cores, lib=lib)
-    t1 = time.perf_counter() - t0
-    spp = int(max(1, min(cfg["samples"], round(target_seconds / max(t1, 1e-3)))))
-    t0 = time.perf_counter()
-    r = _oracle.render(hs, w, h, spp, b, n_threads=cores, lib=lib)
-    dt = time.perf_counter() - t0
-    rays = r["counters"]["rays"]
-    # per-core figure (SURVEY.md section 8d asks for T = all threads and T = 1): 2 spp of the same frame on one thread
-    t0 = time.perf_counter()
-    r1 = _oracle.render(hs, w, h, 2, b, n_threads=1, lib=lib)
-    dt1 = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "single_thread_mray_per_s": r1["counters"]["rays"] / dt1 / 1e6,
-            "sample": f"{cfg['asset']} {w}x{h}, {spp} of {cfg['samples']} spp, {b} bounces, {dt:.1f} s, "
-                      f"oracle -O3 -march=native, {cores} threads",
-            "msample_per_s": w * h * spp / dt / 1e6}
+    simd = bool(lib.oracle_have_avx2())
+
+    def timed(spp, threads):
+        t0 = time.perf_counter()
+        r = _oracle.render(hs, w, h, spp, b, n_threads=threads, lib=lib)
+        return r["counters"]["rays"], time.perf_counter() - t0
+
+    def measure(mode, seconds):
+        lib.oracle_set_simd(mode)
+        _, t1 = timed(1, cores)
+        spp = int(max(1, min(cfg["samples"], round(seconds / max(t1, 1e-3)))))
+        rays, dt = timed(spp, cores)
+        rays1, dt1 = timed(2, 1)           # per-core figure (T = all threads and T = 1)
+        return dict(mray_per_s=rays / dt / 1e6, single_thread_mray_per_s=rays1 / dt1 / 1e6, spp=spp, seconds=dt,
+                    msample_per_s=w * h * spp / dt / 1e6)
+
+    try:
+        main = measure(1 if simd else 0, target_seconds)
+        scalar = measure(0, target_seconds / 3.0) if simd else main
+    finally:
+        lib.oracle_set_simd(1)
+    form = "8-wide AVX2 forms of the reference's SIMD routines" if simd else "scalar restatement (no AVX2 on this host)"
+    return {"value": main["mray_per_s"], "unit": "Mray/s", "cores": cores, "kind": "port-avx2" if simd else "port",
+            "single_thread_mray_per_s": main["single_thread_mray_per_s"],
+            "sample": f"{cfg['asset']} {w}x{h}, {main['spp']} of {cfg['samples']} spp, {b} bounces, {main['seconds']:.1f} s, "
+                      f"oracle -O3 -march=native ({form}), {cores} threads",
+            "msample_per_s": main["msample_per_s"],
+            "scalar": {"kind": "port", "value": scalar["mray_per_s"], "single_thread_mray_per_s": scalar["single_thread_mray_per_s"],
+                       "sample": f"{scalar['spp']} spp, {scalar['seconds']:.1f} s"}}
 
 
 def measured_profile(workload):

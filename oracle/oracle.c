@@ -47,9 +47,19 @@ static f32 min_f32x8(f32 const vec[8], f32 epsilon, i32 *index) {
 
 /* raytracer.c:84-188  Moeller-Trumbore against the 8 triangles of one leaf
  * group; no determinant test; epsilon-padded barycentric bounds; t >= eps.    */
-static bool ray_triangles_hit_8(Ray const *ray, Triangles const *triangles, isize offset, Hit *hit, i32 *lane_out) {
+static bool ray_triangles_hit_8_fill(Ray const *ray, Triangles const *triangles, isize offset, Hit *hit, i32 *lane_out,
+                                     f32 const us[8], f32 const vs[8], f32 const distances[8]);
+#if defined(__AVX2__) && (defined(__FMA__) || defined(RT_MATH_NO_FMA))
+#define ORACLE_HAVE_AVX2 1
+static int g_oracle_simd = 1;
+static f32 min_f32x8_avx2(f32 const vec[8], f32 epsilon, i32 *index);
+#else
+#define ORACLE_HAVE_AVX2 0
+static int g_oracle_simd = 0;
+#endif
+
+static void ray_triangles_8_scalar(Ray const *ray, Triangles const *triangles, isize offset, f32 us[8], f32 vs[8], f32 distances[8]) {
   rt_v3 dir = V(ray->direction), org = V(ray->position);
-  f32 us[8], vs[8], distances[8];
 
   for (int k = 0; k < 8; k++) {
     isize i = offset + k;
@@ -78,9 +88,19 @@ static bool ray_triangles_hit_8(Ray const *ray, Triangles const *triangles, isiz
     vs[k] = v;
     distances[k] = miss ? RT_INF : t;
   }
+}
 
+/* raytracer.c:157-187: horizontal minimum, closer-hit test and the fill of `Hit` (scalar in the reference as well) */
+static bool ray_triangles_hit_8_fill(Ray const *ray, Triangles const *triangles, isize offset, Hit *hit, i32 *lane_out,
+                                     f32 const us[8], f32 const vs[8], f32 const distances[8]) {
+  rt_v3 dir = V(ray->direction), org = V(ray->position);
   i32 triangle_index;
-  f32 min = min_f32x8(distances, 0.0f, &triangle_index);
+  f32 min;
+#if ORACLE_HAVE_AVX2
+  if (g_oracle_simd) min = min_f32x8_avx2(distances, 0.0f, &triangle_index);
+  else
+#endif
+    min = min_f32x8(distances, 0.0f, &triangle_index);
 
   if (min < hit->distance) {
     hit->distance = min;
@@ -109,8 +129,134 @@ static bool ray_triangles_hit_8(Ray const *ray, Triangles const *triangles, isiz
   return false;
 }
 
-/* raytracer.c:190-230  slab test of one ray against the 8 child boxes of a node */
+/* ------------------------------------------------------------------------- */
+/* The reference's 8-wide AVX2 forms (raytracer.c:15-32 min_f32x8, :84-188 ray_triangles_hit_8, :190-230
+ * ray_aabbs_hit_8): __m256 arithmetic over the 8 triangles of a leaf group / the 8 child boxes of a node, same operand
+ * order (the NaN rule of _mm256_min_ps / _mm256_max_ps is what rt_min_ps / rt_max_ps emulate in the scalar form), same
+ * numeric contract (rt_math.h: one _mm256_fmadd_ps where the scalar form has one rt_madd).  Bit-identical to the scalar
+ * form by construction and by test (tests/test_oracle_simd.py); the default when the compiler targets AVX2 (+ FMA under
+ * contract v2) -- it is the reference's own SIMD path that bench.py times as `cpu_baseline` (kind "port-avx2"). */
+#if ORACLE_HAVE_AVX2
+static inline __m256 mm_madd(__m256 a, __m256 b, __m256 c) {
+#ifdef RT_MATH_NO_FMA
+  return _mm256_add_ps(_mm256_mul_ps(a, b), c);
+#else
+  return _mm256_fmadd_ps(a, b, c);
+#endif
+}
+static inline __m256 mm_neg(__m256 a) { return _mm256_xor_ps(a, _mm256_set1_ps(-0.0f)); }
+static inline __m256 mm_dot3(__m256 a0, __m256 b0, __m256 a1, __m256 b1, __m256 a2, __m256 b2) {      /* rt_dot3 */
+  return mm_madd(a2, b2, mm_madd(a1, b1, _mm256_mul_ps(a0, b0)));
+}
+static inline __m256 mm_diff2(__m256 a, __m256 b, __m256 c, __m256 d) {                                /* rt_diff2 */
+  return mm_madd(a, b, mm_neg(_mm256_mul_ps(c, d)));
+}
+
+/* raytracer.c:84-156 */
+static void ray_triangles_8_avx2(Ray const *ray, Triangles const *triangles, isize offset, f32 us[8], f32 vs[8], f32 distances[8]) {
+  __m256 dx = _mm256_set1_ps(ray->direction.x), dy = _mm256_set1_ps(ray->direction.y), dz = _mm256_set1_ps(ray->direction.z);
+  __m256 ox = _mm256_set1_ps(ray->position.x), oy = _mm256_set1_ps(ray->position.y), oz = _mm256_set1_ps(ray->position.z);
+  __m256 ax = _mm256_loadu_ps(triangles->x[0] + offset), ay = _mm256_loadu_ps(triangles->y[0] + offset), az = _mm256_loadu_ps(triangles->z[0] + offset);
+  __m256 bx = _mm256_loadu_ps(triangles->x[1] + offset), by = _mm256_loadu_ps(triangles->y[1] + offset), bz = _mm256_loadu_ps(triangles->z[1] + offset);
+  __m256 cx = _mm256_loadu_ps(triangles->x[2] + offset), cy = _mm256_loadu_ps(triangles->y[2] + offset), cz = _mm256_loadu_ps(triangles->z[2] + offset);
+  __m256 e1x = _mm256_sub_ps(bx, ax), e1y = _mm256_sub_ps(by, ay), e1z = _mm256_sub_ps(bz, az);
+  __m256 e2x = _mm256_sub_ps(cx, ax), e2y = _mm256_sub_ps(cy, ay), e2z = _mm256_sub_ps(cz, az);
+  /* ray_cross_e2 = cross(dir, edge2) */
+  __m256 rx = mm_diff2(dy, e2z, dz, e2y), ry = mm_diff2(dz, e2x, dx, e2z), rz = mm_diff2(dx, e2y, dy, e2x);
+  __m256 det = mm_dot3(e1x, rx, e1y, ry, e1z, rz);
+  __m256 inv_det = _mm256_div_ps(_mm256_set1_ps(1.0f), det);
+  __m256 sx = _mm256_sub_ps(ox, ax), sy = _mm256_sub_ps(oy, ay), sz = _mm256_sub_ps(oz, az);
+  /* s_cross_e1 = cross(s, edge1) */
+  __m256 qx = mm_diff2(sy, e1z, sz, e1y), qy = mm_diff2(sz, e1x, sx, e1z), qz = mm_diff2(sx, e1y, sy, e1x);
+  __m256 u = _mm256_mul_ps(inv_det, mm_dot3(sx, rx, sy, ry, sz, rz));
+  __m256 v = _mm256_mul_ps(inv_det, mm_dot3(dx, qx, dy, qy, dz, qz));
+  __m256 t = _mm256_mul_ps(inv_det, mm_dot3(e2x, qx, e2y, qy, e2z, qz));
+  __m256 eps = _mm256_set1_ps(RT_EPS), neg_eps = _mm256_set1_ps(-RT_EPS), one_eps = _mm256_set1_ps(1.0f + RT_EPS);
+  __m256 miss = _mm256_cmp_ps(u, neg_eps, _CMP_LT_OQ);
+  miss = _mm256_or_ps(miss, _mm256_cmp_ps(u, one_eps, _CMP_GT_OQ));
+  miss = _mm256_or_ps(miss, _mm256_cmp_ps(v, neg_eps, _CMP_LT_OQ));
+  miss = _mm256_or_ps(miss, _mm256_cmp_ps(_mm256_add_ps(u, v), one_eps, _CMP_GT_OQ));
+  miss = _mm256_or_ps(miss, _mm256_cmp_ps(t, eps, _CMP_LT_OQ));
+  _mm256_storeu_ps(us, u);
+  _mm256_storeu_ps(vs, v);
+  _mm256_storeu_ps(distances, _mm256_blendv_ps(t, _mm256_set1_ps(RT_INF), miss));
+}
+
+/* raytracer.c:190-230 */
+static void ray_aabbs_hit_8_avx2(Ray const *ray, f32 t_min, f32 t_max, BVH_Node const *node, f32 *distances) {
+  f32 inv_x = 1.0f / ray->direction.x, inv_y = 1.0f / ray->direction.y, inv_z = 1.0f / ray->direction.z;
+  f32 ox = ray->position.x, oy = ray->position.y, oz = ray->position.z;
+  f32 bias_x = rt_slab_bias(ox, inv_x), bias_y = rt_slab_bias(oy, inv_y), bias_z = rt_slab_bias(oz, inv_z);
+  bool fast = rt_slab_fast(inv_x, inv_y, inv_z, bias_x, bias_y, bias_z);
+  __m256 ix = _mm256_set1_ps(inv_x), iy = _mm256_set1_ps(inv_y), iz = _mm256_set1_ps(inv_z);
+  __m256 mnx = _mm256_loadu_ps(node->min_x), mny = _mm256_loadu_ps(node->min_y), mnz = _mm256_loadu_ps(node->min_z);
+  __m256 mxx = _mm256_loadu_ps(node->max_x), mxy = _mm256_loadu_ps(node->max_y), mxz = _mm256_loadu_ps(node->max_z);
+  __m256 t0x, t0y, t0z, t1x, t1y, t1z;
+#ifndef RT_MATH_NO_FMA
+  if (fast) {                                   /* rt_slab_t_fast: fma(plane, inv, -(o * inv)) */
+    __m256 bx = _mm256_set1_ps(bias_x), by = _mm256_set1_ps(bias_y), bz = _mm256_set1_ps(bias_z);
+    t0x = _mm256_fmadd_ps(mnx, ix, bx); t0y = _mm256_fmadd_ps(mny, iy, by); t0z = _mm256_fmadd_ps(mnz, iz, bz);
+    t1x = _mm256_fmadd_ps(mxx, ix, bx); t1y = _mm256_fmadd_ps(mxy, iy, by); t1z = _mm256_fmadd_ps(mxz, iz, bz);
+  } else
+#endif
+  {                                             /* rt_slab_t_exact: (plane - o) * inv, raytracer.c:203-208 */
+    (void)fast;
+    __m256 vx = _mm256_set1_ps(ox), vy = _mm256_set1_ps(oy), vz = _mm256_set1_ps(oz);
+    t0x = _mm256_mul_ps(_mm256_sub_ps(mnx, vx), ix); t0y = _mm256_mul_ps(_mm256_sub_ps(mny, vy), iy); t0z = _mm256_mul_ps(_mm256_sub_ps(mnz, vz), iz);
+    t1x = _mm256_mul_ps(_mm256_sub_ps(mxx, vx), ix); t1y = _mm256_mul_ps(_mm256_sub_ps(mxy, vy), iy); t1z = _mm256_mul_ps(_mm256_sub_ps(mxz, vz), iz);
+  }
+  __m256 sx = _mm256_min_ps(t0x, t1x), sy = _mm256_min_ps(t0y, t1y), sz = _mm256_min_ps(t0z, t1z);
+  __m256 bx2 = _mm256_max_ps(t0x, t1x), by2 = _mm256_max_ps(t0y, t1y), bz2 = _mm256_max_ps(t0z, t1z);
+  __m256 t_minv = _mm256_max_ps(_mm256_set1_ps(t_min), _mm256_max_ps(sx, _mm256_max_ps(sy, sz)));
+  __m256 t_maxv = _mm256_min_ps(_mm256_set1_ps(t_max), _mm256_min_ps(bx2, _mm256_min_ps(by2, bz2)));
+  __m256 miss = _mm256_cmp_ps(t_minv, t_maxv, _CMP_GE_OQ);
+  _mm256_storeu_ps(distances, _mm256_blendv_ps(t_minv, _mm256_set1_ps(RT_INF), miss));
+}
+#endif
+
+#if ORACLE_HAVE_AVX2
+/* raytracer.c:15-32: lanes that are not > epsilon (NaN included) become +inf; horizontal minimum by three
+ * shuffle + min steps; index of the LOWEST lane equal to the minimum */
+static f32 min_f32x8_avx2(f32 const vec[8], f32 epsilon, i32 *index) {
+  __m256 v = _mm256_loadu_ps(vec);
+  __m256 inf = _mm256_set1_ps(RT_INF);
+  __m256 s = _mm256_blendv_ps(inf, v, _mm256_cmp_ps(v, _mm256_set1_ps(epsilon), _CMP_GT_OQ));
+  __m256 m = _mm256_min_ps(s, _mm256_permute2f128_ps(s, s, 1));
+  m = _mm256_min_ps(m, _mm256_shuffle_ps(m, m, _MM_SHUFFLE(1, 0, 3, 2)));
+  m = _mm256_min_ps(m, _mm256_shuffle_ps(m, m, _MM_SHUFFLE(2, 3, 0, 1)));
+  int mask = _mm256_movemask_ps(_mm256_cmp_ps(s, m, _CMP_EQ_OQ));
+  *index = mask ? __builtin_ctz((unsigned)mask) : 0;
+  return _mm256_cvtss_f32(m);
+}
+#endif
+
+int oracle_have_avx2(void) { return ORACLE_HAVE_AVX2; }
+/* 1 = the 8-wide AVX2 forms (default when compiled for AVX2), 0 = the scalar restatement; returns the mode now in force */
+int oracle_set_simd(int on) {
+  g_oracle_simd = (on && ORACLE_HAVE_AVX2) ? 1 : 0;
+  return g_oracle_simd;
+}
+
+static bool ray_triangles_hit_8(Ray const *ray, Triangles const *triangles, isize offset, Hit *hit, i32 *lane_out) {
+  f32 us[8], vs[8], distances[8];
+#if ORACLE_HAVE_AVX2
+  if (g_oracle_simd) ray_triangles_8_avx2(ray, triangles, offset, us, vs, distances);
+  else
+#endif
+    ray_triangles_8_scalar(ray, triangles, offset, us, vs, distances);
+  return ray_triangles_hit_8_fill(ray, triangles, offset, hit, lane_out, us, vs, distances);
+}
+
+static void ray_aabbs_hit_8_scalar(Ray const *ray, f32 t_min, f32 t_max, BVH_Node const *node, f32 *distances);
 static void ray_aabbs_hit_8(Ray const *ray, f32 t_min, f32 t_max, BVH_Node const *node, f32 *distances) {
+#if ORACLE_HAVE_AVX2
+  if (g_oracle_simd) { ray_aabbs_hit_8_avx2(ray, t_min, t_max, node, distances); return; }
+#endif
+  ray_aabbs_hit_8_scalar(ray, t_min, t_max, node, distances);
+}
+
+/* raytracer.c:190-230  slab test of one ray against the 8 child boxes of a node (scalar form) */
+static void ray_aabbs_hit_8_scalar(Ray const *ray, f32 t_min, f32 t_max, BVH_Node const *node, f32 *distances) {
   f32 inv_x = 1.0f / ray->direction.x;
   f32 inv_y = 1.0f / ray->direction.y;
   f32 inv_z = 1.0f / ray->direction.z;

@@ -119,6 +119,12 @@ void oracle_lightmap_bake(Image const *lightmap, Scene const *scene, isize sampl
  * u8 images of equal size (components >= 3 are filtered, like min(components, 3) in denoiser.c:24,36) */
 void oracle_denoise_image(Image const *src, Image const *dst);
 
+/* The reference's 8-wide AVX2 forms of min_f32x8 / ray_triangles_hit_8 / ray_aabbs_hit_8 (raytracer.c:15-32,84-230) are the
+ * default when the checker is compiled for AVX2 (+ FMA under numeric contract v2); the scalar restatement stays selectable
+ * and must give the same bits (tests/test_oracle_simd.py).  oracle_set_simd returns the mode now in force; process-wide. */
+int oracle_have_avx2(void);
+int oracle_set_simd(int on);
+
 #ifdef __cplusplus
 }
 #endif

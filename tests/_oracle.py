@@ -76,6 +76,9 @@ def load(path=None):
     d.oracle_denoise_image.restype = None
     d.oracle_encode_u8.argtypes = [C.c_float]
     d.oracle_encode_u8.restype = C.c_uint8
+    d.oracle_have_avx2.restype = C.c_int
+    d.oracle_set_simd.argtypes = [C.c_int]
+    d.oracle_set_simd.restype = C.c_int
     if path is None:
         _dll = d
     return d
