@@ -53,7 +53,7 @@ int rt_launch_lightmap(const RT_KParams *P, const float *verts, int n_tris, int 
                        int samples, int *owner, uint8_t *pixels, hipStream_t stream);
 int rt_launch_denoise(int width, int height, int src_stride, int src_comp, int dst_stride, int dst_comp,
                       const uint8_t *src, uint8_t *dst, hipStream_t stream);
-int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
+int rt_launch_pack_texture(const uint8_t *raw, int width, int rows, int y0, int stride, int comp, uint32_t *out,
                            hipStream_t stream);
 #ifdef RT_DIAG_VARIANTS
 // rt_wavefront.hip
@@ -455,8 +455,13 @@ static int texture_index(Image const *img, TexturePool &pool) {
   t.offset = (uint32_t)pool.texels;
   t.width = (int32_t)img->width;
   t.height = (int32_t)img->height;
+#if RT_TEX_TILED
+  t.stride = (int32_t)((img->width + 3) / 4);                                  // tiles per row (rt_device.h)
+  pool.texels += (size_t)t.stride * (size_t)((img->height + 3) / 4) * 16;
+#else
   t.stride = (int32_t)img->width;
   pool.texels += (size_t)img->width * img->height;
+#endif
   int idx = (int)pool.descs.size();
   pool.descs.push_back(t);
   pool.sources.push_back(img);
@@ -482,7 +487,7 @@ static int upload_textures(const TexturePool &pool, uint32_t **d_texels, int64_t
     const Image *img = pool.sources[k];
     size_t raw = (size_t)img->stride * img->height * img->components;
     rc = (int)hipMemcpy(stage, img->pixels.data, raw, hipMemcpyHostToDevice);
-    if (rc == 0) rc = rt_launch_pack_texture(stage, (int)img->width, (int)img->height, (int)img->stride, (int)img->components,
+    if (rc == 0) rc = rt_launch_pack_texture(stage, (int)img->width, (int)img->height, 0, (int)img->stride, (int)img->components,
                                              *d_texels + pool.descs[k].offset, nullptr);
     if (rc == 0) rc = (int)hipDeviceSynchronize();        // the staging buffer is reused by the next texture
   }
@@ -688,13 +693,24 @@ static void build_tri_record(const Triangle_AOS &a, int mat, float *r) {
   r[20] = a.bitangent.x; r[21] = a.bitangent.y; r[22] = a.bitangent.z; r[23] = a.tex_coords_c.x;
   r[24] = a.tex_coords_c.y; r[25] = 0.0f; r[26] = 0.0f; r[27] = 0.0f;
 }
-static void build_material_row(const PBR_Shader_Data *d, int ta, int tn, int tm, int te, int kind, float *m) {
+static void build_material_row(const PBR_Shader_Data *d, int ta, int tn, int tm, int te, int kind,
+                               const std::vector<RT_DTexture> &descs, float *m) {
   const float row[20] = {d->base_color.x, d->base_color.y, d->base_color.z, d->roughness,
                          d->emission.x, d->emission.y, d->emission.z, d->metalness,
                          d->normal_map_strength, d->sheen, d->sheen_tint, d->anisotropic_strength,
                          int_bits(ta), int_bits(tn), int_bits(tm), int_bits(te),
                          int_bits(kind), 0.0f, 0.0f, 0.0f};
   memcpy(m, row, sizeof row);
+  const int tex[4] = {ta, tn, tm, te};
+  for (int k = 0; k < 4; k++) {
+    float *q = m + 20 + 4 * k;
+    if (tex[k] >= 0 && (size_t)tex[k] < descs.size()) {
+      const RT_DTexture &t = descs[(size_t)tex[k]];
+      q[0] = int_bits((int32_t)t.offset); q[1] = int_bits(t.width); q[2] = int_bits(t.height); q[3] = int_bits(t.stride);
+    } else {
+      q[0] = q[1] = q[2] = q[3] = 0.0f;
+    }
+  }
 }
 
 static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
@@ -763,10 +779,10 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
           rt_fail("rt_scene_upload: material of triangle %d references an unusable Image (need PT_u8, >= 3 components, pixels.len >= stride*height*components)", i);
           return nullptr;
         }
-        mat = (int)(mats.size() / 20);
-        float m[20];
-        build_material_row(d, ta, tn, tm, te, kind, m);
-        mats.insert(mats.end(), m, m + 20);
+        mat = (int)(mats.size() / RT_MAT_FLOATS);
+        float m[RT_MAT_FLOATS];
+        build_material_row(d, ta, tn, tm, te, kind, pool.descs, m);
+        mats.insert(mats.end(), m, m + RT_MAT_FLOATS);
         mat_map[key] = mat;
         mat_ptrs.push_back(a.shader.data);
         mat_first_tri.push_back(i);
@@ -774,7 +790,7 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
     }
     build_tri_record(a, mat, &tris[(size_t)i * 28]);
   }
-  if (mats.empty()) mats.resize(20, 0.0f);
+  if (mats.empty()) mats.resize(RT_MAT_FLOATS, 0.0f);
 
   // leaf tiles (build_leaf_tile)
   const int n_groups = n / 8;
@@ -821,7 +837,7 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
   d->n_triangles = n;
   d->max_edge = max_edge;
   d->boxes_ordered = boxes_ordered;
-  d->n_materials = (int32_t)(mats.size() / 20);
+  d->n_materials = (int32_t)(mats.size() / RT_MAT_FLOATS);
   d->n_textures = (int32_t)pool.descs.size();
   d->mat_ptrs = mat_ptrs;
   d->mat_first_tri = mat_first_tri;
@@ -964,9 +980,9 @@ static int touch_device_scene(RT_Device_Scene *d, Scene const *scene, const void
     bool any = false;
     for (auto &kv : d->mat_map) {                                        // the record may serve both kinds
       if ((const void *)(uintptr_t)(kv.first / 2u) != d->mat_ptrs[k]) continue;
-      float row[20];
-      build_material_row(m, ta, tn, tm, te, (int)(kv.first & 1u), row);
-      HIP_TRY(hipMemcpy(d->mats + (size_t)kv.second * 20, row, sizeof row, hipMemcpyHostToDevice));
+      float row[RT_MAT_FLOATS];
+      build_material_row(m, ta, tn, tm, te, (int)(kv.first & 1u), d->tex_descs, row);
+      HIP_TRY(hipMemcpy(d->mats + (size_t)kv.second * RT_MAT_FLOATS, row, sizeof row, hipMemcpyHostToDevice));
       any = true;
     }
     return any ? 1 : 0;
@@ -982,8 +998,12 @@ static int touch_device_scene(RT_Device_Scene *d, Scene const *scene, const void
     DevBuf stage;
     HIP_TRY(stage.alloc((r1 - r0) * row_bytes));
     HIP_TRY(hipMemcpy(stage.p, (const unsigned char *)img->pixels.data + r0 * row_bytes, (r1 - r0) * row_bytes, hipMemcpyHostToDevice));
-    int rc = rt_launch_pack_texture(stage.as<uint8_t>(), (int)img->width, (int)(r1 - r0), (int)img->stride, (int)img->components,
-                                    d->texels + desc.offset + r0 * (size_t)desc.width, nullptr);
+    uint32_t *tex_base = d->texels + desc.offset;
+#if !RT_TEX_TILED
+    tex_base += r0 * (size_t)desc.width;           // (row-major: the kernel's row 0 is row r0 of the texture)
+#endif
+    int rc = rt_launch_pack_texture(stage.as<uint8_t>(), (int)img->width, (int)(r1 - r0), RT_TEX_TILED ? (int)r0 : 0, (int)img->stride,
+                                    (int)img->components, tex_base, nullptr);
     if (rc == 0) rc = (int)hipDeviceSynchronize();
     if (rc != 0) return rt_fail("rt_scene_touch: texture rows: %s", hipGetErrorString((hipError_t)rc));
     return 1;

@@ -593,6 +593,57 @@ __device__ __forceinline__ rt_v3 texel_rgb(uint32_t t) {
                     (float)(int)((t >> 16) & 0xFFu) * k);
 }
 
+// sample_texture_bilinear (driver.c:49-93) in three steps, so that a caller with several textures can put ALL their texel
+// loads in flight before it consumes the first one (shade(): 16 loads, one wait, instead of four dependent round trips):
+//   tex_taps()    wrap rules, the four texel indices and the two weights
+//   tex_fetch()   the four loads
+//   tex_combine() u8 / 255.999, lerp x then y (same order, same bits as before)
+struct TexTaps { int i00, i10, i01, i11; float a, b; };
+struct TexQuad { uint32_t q00, q10, q01, q11; };
+
+__device__ __forceinline__ TexTaps tex_taps(const RT_DTexture &T, float tx, float ty) {
+  if (tx < 0) tx += (float)(-(int)tx + 1);
+  if (ty < 0) ty += (float)(-(int)ty + 1);
+  tx = rt_fractf(tx);
+  ty = rt_fractf(ty);
+  float px = tx * (float)T.width;
+  float py = ty * (float)T.height;
+  int u = (int)px, v = (int)py;
+  if (u > T.width - 1) u = T.width - 1;
+  if (v > T.height - 1) v = T.height - 1;
+  TexTaps t;
+  t.a = px - (float)u;
+  t.b = py - (float)v;
+#if RT_TEX_TILED
+  // 4 x 4 tiles (rt_device.h): the neighbour to the right is the next texel of the tile, or the first of the tile's row in
+  // the next tile (+ 16 - 3); the one below the next row of the tile, or the first row of the tile below; clamp to edge = 0
+  const int du = (u + 1 < T.width) ? (((u & 3) == 3) ? 13 : 1) : 0;
+  const int dv = (v + 1 < T.height) ? (((v & 3) == 3) ? T.stride * 16 - 12 : 4) : 0;
+  t.i00 = RT_TEX_TILE_INDEX(u, v, T.stride);
+  t.i10 = t.i00 + du;
+  t.i01 = t.i00 + dv;
+  t.i11 = t.i00 + du + dv;
+#else
+  int u2 = (u + 1 < T.width) ? u + 1 : u;
+  int v2 = (v + 1 < T.height) ? v + 1 : v;
+  t.i00 = u + T.stride * v;
+  t.i10 = u2 + T.stride * v;
+  t.i01 = u + T.stride * v2;
+  t.i11 = u2 + T.stride * v2;
+#endif
+  return t;
+}
+__device__ __forceinline__ TexQuad tex_fetch(const uint32_t *tp, const TexTaps &t) {
+  TexQuad q;
+  q.q00 = tp[t.i00]; q.q10 = tp[t.i10]; q.q01 = tp[t.i01]; q.q11 = tp[t.i11];
+  return q;
+}
+__device__ __forceinline__ rt_v3 tex_combine(const TexQuad &q, const TexTaps &t) {
+  rt_v3 c0 = rt_v3_lerp(texel_rgb(q.q00), texel_rgb(q.q10), t.a);
+  rt_v3 c1 = rt_v3_lerp(texel_rgb(q.q01), texel_rgb(q.q11), t.a);
+  return rt_v3_lerp(c0, c1, t.b);
+}
+
 template <class PT>
 __device__ __forceinline__ rt_v3 tex_bilinear(const PT &P, int tex, float tx, float ty) {
   RT_DTexture T;
@@ -611,27 +662,9 @@ __device__ __forceinline__ rt_v3 tex_bilinear(const PT &P, int tex, float tx, fl
 #else
   T = P.textures[tex];
 #endif
-  if (tx < 0) tx += (float)(-(int)tx + 1);
-  if (ty < 0) ty += (float)(-(int)ty + 1);
-  tx = rt_fractf(tx);
-  ty = rt_fractf(ty);
-  float px = tx * (float)T.width;
-  float py = ty * (float)T.height;
-  int u = (int)px, v = (int)py;
-  if (u > T.width - 1) u = T.width - 1;
-  if (v > T.height - 1) v = T.height - 1;
-  float a = px - (float)u;
-  float b = py - (float)v;
-  int u2 = (u + 1 < T.width) ? u + 1 : u;
-  int v2 = (v + 1 < T.height) ? v + 1 : v;
-  const uint32_t *tp = P.texels + T.offset;
-  rt_v3 c00 = texel_rgb(tp[u + T.stride * v]);
-  rt_v3 c10 = texel_rgb(tp[u2 + T.stride * v]);
-  rt_v3 c01 = texel_rgb(tp[u + T.stride * v2]);
-  rt_v3 c11 = texel_rgb(tp[u2 + T.stride * v2]);
-  rt_v3 c0 = rt_v3_lerp(c00, c10, a);
-  rt_v3 c1 = rt_v3_lerp(c01, c11, a);
-  return rt_v3_lerp(c0, c1, b);
+  const TexTaps t = tex_taps(T, tx, ty);
+  const TexQuad q = tex_fetch(P.texels + T.offset, t);
+  return tex_combine(q, t);
 }
 
 // rt_srgb_to_linear() of a bilinear texture sample: (x + 0.055f) / 1.055f as a multiplication by RN(1 / 1.055f) corrected
@@ -777,11 +810,9 @@ struct ShadeIn {
 };
 
 // driver.c:129-153
-template <class PT>
-__device__ __forceinline__ rt_v3 normal_map(const PT &P, int tex, float strength, const ShadeIn &in) {
+__device__ __forceinline__ rt_v3 normal_map(bool has_map, rt_v3 v, float strength, const ShadeIn &in) {
   rt_v3 normal = in.normal;
-  if (tex >= 0) {
-    rt_v3 v = tex_bilinear(P, tex, in.uvx, in.uvy);
+  if (has_map) {
     v = rt_v3_madd(v, 2.0f, rt_v3_make(-1.0f, -1.0f, -1.0f));
     v.y *= -1.0f;
     rt_v3 t = in.tangent, b = in.bitangent, n = in.normal;
@@ -799,33 +830,58 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
                                       rt_v3 &out_dir, rt_v3 &tint, rt_v3 &emission, bool &terminate,
                                       LaneCounters &cn) {
   float4 m0, m1, m2, m3, m4;
+  RT_DTexture D[4];              // albedo, normal, metal_roughness, emission: embedded in the material record (rt_device.h)
 #if RT_SCALAR_MATS
-  // one material for every lane of this block (the helmet has one material, most blocks of any scene have one): the 80-byte
-  // record comes through the scalar cache -- one round trip of ~100 cycles instead of a vector load's several hundred --
-  // and the texture indices it holds are wave-uniform
+  // one material for every lane of this block (the helmet has one material, most blocks of any scene have one): the
+  // record -- parameters AND the descriptors of its four textures -- comes through the scalar cache in ONE round trip
+  // (~100 cycles instead of a vector load's several hundred, and no second dependent load for the descriptors)
   const int mat0 = __builtin_amdgcn_readfirstlane(mat);
   if (__ballot(mat != mat0) == 0ull) {
-    cfloat *sb = as_scalar_ptr(P.mats) + (size_t)mat0 * 20;
+    cfloat *sb = as_scalar_ptr(P.mats) + (size_t)mat0 * RT_MAT_FLOATS;
     m0 = make_float4(sb[0], sb[1], sb[2], sb[3]);
     m1 = make_float4(sb[4], sb[5], sb[6], sb[7]);
     m2 = make_float4(sb[8], sb[9], sb[10], sb[11]);
     m3 = make_float4(sb[12], sb[13], sb[14], sb[15]);
     m4 = make_float4(sb[16], sb[17], sb[18], sb[19]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      D[k].offset = (uint32_t)as_i(sb[20 + 4 * k]); D[k].width = as_i(sb[21 + 4 * k]); D[k].height = as_i(sb[22 + 4 * k]); D[k].stride = as_i(sb[23 + 4 * k]);
+    }
   } else
 #endif
   {
-    const float *mb = P.mats + (size_t)mat * 20;
+    const float *mb = P.mats + (size_t)mat * RT_MAT_FLOATS;
     m0 = ld4(mb, 0); m1 = ld4(mb, 1); m2 = ld4(mb, 2); m3 = ld4(mb, 3); m4 = ld4(mb, 4);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float4 dk = ld4(mb, 5 + k);
+      D[k].offset = (uint32_t)as_i(dk.x); D[k].width = as_i(dk.y); D[k].height = as_i(dk.z); D[k].stride = as_i(dk.w);
+    }
   }
   int tex_albedo = as_i(m3.x), tex_normal = as_i(m3.y), tex_mr = as_i(m3.z), tex_em = as_i(m3.w);
   int kind = as_i(m4.x);
 
-  rt_v3 normal = normal_map(P, tex_normal, m2.x, in);
+  // RT_TEX_BATCH: how many of the material's four texture fetches have their loads in flight together.  1 = one after the
+  // other (four dependent round trips of four texels, round 3), 2 = normal + albedo, then metal-roughness + emission,
+  // 4 = all sixteen loads before the first is consumed.  Same arithmetic in every case.
+#ifndef RT_TEX_BATCH
+#define RT_TEX_BATCH 2
+#endif
+  const bool dbg = kind == RT_MAT_DEBUG;
+  const bool ha = tex_albedo >= 0 && !dbg, hn = tex_normal >= 0, hm = tex_mr >= 0 && !dbg, he = tex_em >= 0 && !dbg;
+  TexTaps tn, ta, tm, te;
+  TexQuad qn, qa, qm, qe;
+  if (hn) { tn = tex_taps(D[1], in.uvx, in.uvy); qn = tex_fetch(P.texels + D[1].offset, tn); }
+  if (RT_TEX_BATCH >= 2 && ha) { ta = tex_taps(D[0], in.uvx, in.uvy); qa = tex_fetch(P.texels + D[0].offset, ta); }
+  if (RT_TEX_BATCH >= 4 && hm) { tm = tex_taps(D[2], in.uvx, in.uvy); qm = tex_fetch(P.texels + D[2].offset, tm); }
+  if (RT_TEX_BATCH >= 4 && he) { te = tex_taps(D[3], in.uvx, in.uvy); qe = tex_fetch(P.texels + D[3].offset, te); }
+
+  rt_v3 normal = normal_map(hn, hn ? tex_combine(qn, tn) : rt_v3_make(0, 0, 0), m2.x, in);
   terminate = false;
   tint = rt_v3_make(0, 0, 0);
   out_dir = rt_v3_make(0, 0, 0);
 
-  if (kind == RT_MAT_DEBUG) {
+  if (dbg) {
     emission = rt_v3_madd(normal, 0.5f, rt_v3_make(0.5f, 0.5f, 0.5f));
     terminate = true;
     return;
@@ -833,12 +889,16 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
 
   if (tex_albedo >= 0 || tex_normal >= 0 || tex_mr >= 0 || tex_em >= 0) cn.textured += 1;
 
+  if (RT_TEX_BATCH < 2 && ha) { ta = tex_taps(D[0], in.uvx, in.uvy); qa = tex_fetch(P.texels + D[0].offset, ta); }
+  if (RT_TEX_BATCH == 2 && hm) { tm = tex_taps(D[2], in.uvx, in.uvy); qm = tex_fetch(P.texels + D[2].offset, tm); }
+  if (RT_TEX_BATCH == 2 && he) { te = tex_taps(D[3], in.uvx, in.uvy); qe = tex_fetch(P.texels + D[3].offset, te); }
   rt_v3 base_color = rt_v3_make(m0.x, m0.y, m0.z);
-  if (tex_albedo >= 0) base_color = rt_v3_mul(base_color, srgb_to_linear_tex(tex_bilinear(P, tex_albedo, in.uvx, in.uvy)));
+  if (ha) base_color = rt_v3_mul(base_color, srgb_to_linear_tex(tex_combine(qa, ta)));
 
   float roughness = m0.w, metalness = m1.w;
-  if (tex_mr >= 0) {
-    rt_v3 mr = tex_bilinear(P, tex_mr, in.uvx, in.uvy);
+  if (RT_TEX_BATCH < 2 && hm) { tm = tex_taps(D[2], in.uvx, in.uvy); qm = tex_fetch(P.texels + D[2].offset, tm); }
+  if (hm) {
+    rt_v3 mr = tex_combine(qm, tm);
     roughness *= mr.y;
     metalness *= mr.z;
   }
@@ -847,7 +907,8 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   metalness /= 0.9f;
 
   emission = rt_v3_make(m1.x, m1.y, m1.z);
-  if (tex_em >= 0) emission = rt_v3_mul(emission, srgb_to_linear_tex(tex_bilinear(P, tex_em, in.uvx, in.uvy)));
+  if (RT_TEX_BATCH < 2 && he) { te = tex_taps(D[3], in.uvx, in.uvy); qe = tex_fetch(P.texels + D[3].offset, te); }
+  if (he) emission = rt_v3_mul(emission, srgb_to_linear_tex(tex_combine(qe, te)));
 
   // basis(), driver.c:155-164
   rt_v3 t, b;

@@ -21,7 +21,8 @@
 #define RT_NODE_F4   12      /* float4 per node           */
 #define RT_LEAF_F4   18      /* float4 per leaf group     */
 #define RT_TRI_F4     7      /* float4 per triangle record*/
-#define RT_MAT_F4     5      /* float4 per material       */
+#define RT_MAT_F4     9      /* float4 per material       */
+#define RT_MAT_FLOATS 36
 #define RT_MAX_DEPTH  8      /* perm-stack levels in LDS  */
 
 #define RT_MAT_DISNEY 0
@@ -49,12 +50,22 @@
  *  [8] normal_map_strength [9] sheen [10] sheen_tint [11] anisotropic_strength
  *  [12] tex_albedo [13] tex_normal [14] tex_metal_roughness [15] tex_emission (int bits, -1 none)
  *  [16] kind (int bits)  [17..19] pad
+ *  [20..35] the descriptors of the four textures, (offset, width, height, stride) as int bits each, in the order albedo,
+ *           normal, metal_roughness, emission: a copy of textures[tex] so that a shade block needs no third dependent
+ *           load between the material record and the texels (zeros for an absent texture)
  */
 
+/* Texel layout in the pool.  RT_TEX_TILED = 1: 4 x 4-texel tiles of 64 bytes (one cache line), tiles row-major,
+ * `stride` = tiles per row: the 2 x 2 footprint of a bilinear fetch lies in ONE line 9 times in 16 instead of never (two
+ * rows of a row-major image are two lines).  0: row-major, `stride` = texels per row.  Addressing only: same texels. */
+#ifndef RT_TEX_TILED
+#define RT_TEX_TILED 1
+#endif
 typedef struct {
   uint32_t offset;    /* first texel in the pool */
   int32_t  width, height, stride;
 } RT_DTexture;
+#define RT_TEX_TILE_INDEX(x, y, tpr) ((((y) >> 2) * (tpr) + ((x) >> 2)) * 16 + (((y) & 3) << 2) + ((x) & 3))
 
 typedef struct {
   /* scene */

@@ -1168,19 +1168,27 @@ extern "C" int rt_launch_untile(int width, int height, int chunks_x, int n_chunk
   return (int)hipGetLastError();
 }
 
-// raw u8 image rows (stride pixels x comp bytes, comp >= 3) -> RGBA8 words, row-major width x height
-__global__ void rt_pack_texture_kernel(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out) {
+// raw u8 image rows (stride pixels x comp bytes, comp >= 3) -> RGBA8 words in the pool layout of rt_device.h (4 x 4 tiles, or
+// row-major).  `rows` rows starting at row y0 of a texture `width` wide whose first texel is out[0] (rt_scene_touch packs a
+// few rows of a resident texture again).
+__global__ void rt_pack_texture_kernel(const uint8_t *raw, int width, int rows, int y0, int stride, int comp, uint32_t *out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)width * height) return;
-  int y = (int)(i / width), x = (int)(i % width);
-  const uint8_t *p = raw + ((size_t)y * stride + x) * comp;
-  out[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
+  if (i >= (size_t)width * rows) return;
+  int yl = (int)(i / width), x = (int)(i % width);
+  const uint8_t *p = raw + ((size_t)yl * stride + x) * comp;
+  const int y = y0 + yl;
+#if RT_TEX_TILED
+  const size_t o = (size_t)RT_TEX_TILE_INDEX(x, y, (width + 3) >> 2);
+#else
+  const size_t o = (size_t)y * width + x;
+#endif
+  out[o] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
 }
 
-extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int height, int stride, int comp, uint32_t *out,
+extern "C" int rt_launch_pack_texture(const uint8_t *raw, int width, int rows, int y0, int stride, int comp, uint32_t *out,
                                       hipStream_t stream) {
-  size_t n = (size_t)width * height;
-  hipLaunchKernelGGL(rt_pack_texture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, width, height, stride,
+  size_t n = (size_t)width * rows;
+  hipLaunchKernelGGL(rt_pack_texture_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, width, rows, y0, stride,
                      comp, out);
   return (int)hipGetLastError();
 }
