@@ -270,9 +270,10 @@ static int render_and_write(Scene *scene_p, int width, int height, int samples, 
       rt_get_frame_timing(&ft);
       double wall = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
       printf("driver_min: frame %d: host wall %.3f ms (%.1f Msample/s) | library total %.3f = stamp %.3f + upload %.3f + enqueue %.3f ... | "
-             "gpu: clear+prepare %.3f, path kernel %.3f, resolve %.3f, copy to host %.3f\n", f, wall,
+             "gpu: clear+prepare %.3f, path kernel %.3f, resolve %.3f, copy to host %.3f | verify %.3f (host, under the kernel) | "
+             "devices %d, slowest %d, gather %.3f\n", f, wall,
              (double)width * height * samples / wall / 1e3, ft.total_ms, ft.stamp_ms, ft.upload_ms, ft.enqueue_ms, ft.gpu_prep_ms,
-             ft.gpu_path_ms, ft.gpu_resolve_ms, ft.gpu_copy_ms);
+             ft.gpu_path_ms, ft.gpu_resolve_ms, ft.gpu_copy_ms, ft.verify_ms, (int)ft.n_devices, (int)ft.slowest_device, ft.gather_ms);
     }
   }
 

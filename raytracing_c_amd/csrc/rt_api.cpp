@@ -229,6 +229,7 @@ struct Device {
   int        slot = 0, phys = 0;
   bool       ready = false;
   bool       peer_ok = true;                  // slots >= 1: direct copies into slot 0's memory are possible (xGMI peer access)
+  hipStream_t mstream = nullptr;              // multi-device frames: this slot's own stream (slots rehearsed on ONE GPU overlap on it)
   int        num_cus = 0;
   std::mutex mutex;                           // serialises frames, the scene cache and the workspace of this device
   Workspace  ws;
@@ -289,6 +290,7 @@ static int ensure_device(Device &D) {            // D.mutex held (or single-thre
     }
     // (refused: the tiles go through a pinned host buffer, render_frame_multi)
   }
+  if (!D.mstream) HIP_TRY(hipStreamCreateWithFlags(&D.mstream, hipStreamNonBlocking));
   D.ready = true;
   return 0;
 }
@@ -1207,6 +1209,7 @@ static void remap_device_slots() {
       for (hipEvent_t e : W.ev0) (void)hipEventDestroy(e);
       for (hipEvent_t e : W.ev1) (void)hipEventDestroy(e);
       for (int i = 0; i < 5; i++) if (W.ev_frame[i]) (void)hipEventDestroy(W.ev_frame[i]);
+      if (D.mstream) { (void)hipStreamDestroy(D.mstream); D.mstream = nullptr; }
       W = Workspace();
       D.last_counters = nullptr;
     }
@@ -1900,7 +1903,9 @@ static void enqueue_device_frame(MultiFrame &J, int r) {
   RT_Render_Params p = J.base;
   p.rank = r;
   p.world = J.world;
-  hipStream_t stream = nullptr;
+  // every slot works on a stream of its own: on N GPUs that changes nothing; N slots rehearsed on ONE GPU overlap -- the
+  // next slot's workgroups take the CUs the previous slot's last paths leave idle -- instead of queueing N launch tails
+  hipStream_t stream = D.mstream;
   hipError_t e = hipEventRecord(W.ev_frame[0], stream);
   if (e == hipSuccess) e = hipMemsetAsync(W.accum, 0, (size_t)J.w * J.h * 3 * sizeof(unsigned long long), stream);
   if (e != hipSuccess) { device_fail(J, r, hipGetErrorString(e)); return; }
@@ -2007,7 +2012,7 @@ static int render_frame_multi(Scene const *scene, Image const *image, RT_Render_
     break;
   }
   DeviceGuard guard(D0);
-  hipStream_t s0 = nullptr;
+  hipStream_t s0 = D0.mstream;
   const double t_g = now_ms();
   for (int r = 1; r < world; r++) {
     Workspace &W = g_devs[r].ws;
