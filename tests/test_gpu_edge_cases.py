@@ -279,3 +279,53 @@ def test_non_u8_or_short_texture_is_refused(rt):
     d = rt.lib.rt_scene_upload(C.byref(hs.scene))
     assert d, rt.last_error()
     rt.lib.rt_scene_release(d)
+
+
+@pytest.mark.parametrize("tw,th", [(37, 23), (5, 3), (64, 1), (1, 9), (130, 67)])
+def test_textures_whose_size_is_not_a_multiple_of_the_tile(rt, oracle, diag, tw, th):
+    """Textures live in 4x4-texel tiles on the device (rt_device.h, round 4).  Sizes that are no multiple of four, one texel
+    wide or high: every fetch -- wrap, clamp at the last column / row, footprints across tile edges -- equals the oracle's
+    bilinear fetch bit for bit, a frame using the texture equals the oracle's, and rows patched by rt_scene_touch land in
+    the right tiles."""
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.scene import Material, build_scene
+    from tests import _oracle
+    rng = np.random.default_rng(tw * 100 + th)
+    pos = np.array([[[-1, -1, 0], [1, -1, 0], [1, 1, 0]], [[-1, -1, 0], [1, 1, 0], [-1, 1, 0]]], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (2, 3, 1))
+    uv = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32)
+    tex = rng.integers(0, 256, (th, tw, 3), dtype=np.uint8)
+    cam = np.eye(4, dtype=np.float32)
+    cam[2, 3] = 2.5
+    hs = build_scene(pos, nrm, uv, np.zeros(2, np.int32), [Material(base_color=(0.9, 0.8, 0.7), roughness=0.6, texture_albedo=0)],
+                     [tex], cam, 1.0, procedural_background(67, 33))
+    n = 4000
+    uvs = rng.uniform(-2, 2, (n, 2)).astype(np.float32)
+    uvs[:8] = [[0, 0], [1, 1], [0.99999994, 0.99999994], [-1e-9, 0.5], [0.5, -1e-9], [1.0 - 0.5 / tw, 1.0 - 0.5 / th], [0.25, 0.75], [2.5, -0.5]]
+    d = rt.diag.rt_scene_upload(C.byref(hs.scene))
+    assert d, rt.last_error(rt.diag)
+    try:
+        for cimg in (hs.images[0], hs.background_image):
+            want = np.zeros((n, 3), np.float32)
+            for i in range(n):
+                oracle.oracle_sample_texture_bilinear(C.byref(cimg), uvs[i, 0], uvs[i, 1], want[i].ctypes.data)
+            hits = 0
+            for t in (-1, 0, 1):
+                got = np.zeros((n, 3), np.float32)
+                if rt.diag.rt_test_texture(d, t, n, uvs.ctypes.data, got.ctypes.data) != 0:
+                    continue
+                hits += int(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+            assert hits >= 1, "no device texture reproduces the host image's fetches"
+    finally:
+        rt.diag.rt_scene_release(d)
+    w, h, s, b = 40, 32, 8, 3
+    first = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(first["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    # rows r0 .. r1 rewritten in place, told to the library: a partial tile row at the bottom included
+    arr = hs._image_arrays[0]
+    r0, r1 = th // 3, th
+    arr[r0:r1] = 255 - arr[r0:r1]
+    assert rt.lib.rt_scene_touch(C.byref(hs.scene), arr[r0:].ctypes.data, (r1 - r0) * tw * 3) == 0, rt.last_error()
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(got["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    assert not np.array_equal(got["accum"], first["accum"])
