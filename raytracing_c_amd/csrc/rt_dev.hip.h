@@ -92,6 +92,8 @@ enum {
   LG_LEAF_X, LG_LEAF_L, LG_LEAF_CAM, LG_POP_X, LG_POP_L, LG_POP_UP_L, LG_POP_RETEST_L, LG_POP_CAM, LG_POP_UP_X, LG_POP_RETEST_X, LG_POP_DONE_L,
   // group 6: shader-clock cycles (>> 4) per kind of block, summed over waves
   LG_CYC_S, LG_CYC_NODE, LG_CYC_LEAF, LG_CYC_POP, LG_CYC_WAVE, LG_CYC_TILE,
+  // the loop of tiles whose pyramid misses the root (round 4): batches of up to 64 camera paths, primary ray -> environment
+  LG_SKY_X, LG_SKY_L, LG_CYC_SKY,
   LG_N
 };
 // The counters live in MEMORY, one row of 64 dwords per wave (g_ledger, rt_kernels.hip), bumped by lane 0 with atomics that

@@ -289,6 +289,108 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     int  n_parked = 0;                   // hits of this tile waiting in the wave's slice of `park`
     uint32_t *park = cold_args()->park;
 
+#ifndef RT_NO_SKY_LOOP
+    // ================= tiles whose pyramid misses every child of the root: a loop of their own =================
+    // Every camera ray of such a tile (82 % of the camera paths of config #3) costs one node visit that finds no candidate and
+    // goes to the environment -- no traversal state, no phases, no parking, no RNG draw.  The loop below does exactly that for
+    // batches of up to 64 paths: primary ray, environment lookup, sample into the LDS tile; same arithmetic, same counters as
+    // the general loop, which takes over at once -- from the same unit, nothing consumed -- should a ray turn up that is not
+    // NaN-free (such a ray does not take the shortcut: its root visit must be computed, see tile_root_miss).
+    if (tile_root_miss && cold_args()->max_bounces > 0) {
+      RT_KArgs A = cold_args();
+      const int width = A->width, height = A->height, sample_first = A->sample_first, sample_end = A->sample_end;
+      const uint32_t n_sb = (uint32_t)A->n_sample_blocks, gmax = (uint32_t)A->grab_max;
+      PrimaryParams PP;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) PP.cam[i][j] = A->cam[i][j];
+      PP.focal_length = A->focal_length; PP.inv_width = A->inv_width; PP.inv_height = A->inv_height; PP.aspect = A->aspect;
+      ShadeParams SP;
+      SP.tris = nullptr; SP.mats = nullptr; SP.textures = A->textures; SP.texels = A->texels;
+      SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
+      uint32_t *tile_next = A->tile_next, *open_groups = A->open_groups;
+      for (;;) {
+        if (c_next >= c_end) {
+          if (u_cur + 1u < u_end) {
+            u_cur += 1u;
+          } else {
+            uint32_t u0 = 0;
+            if (lane == 0) u0 = atomicAdd(&tile_next[tile_idx], grab);
+            u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)u0);
+            if (u0 >= n_chunks_tile) { tile_open = false; break; }
+            u_cur = u0;
+            u_end = u0 + grab < n_chunks_tile ? u0 + grab : n_chunks_tile;
+            if (u_end == n_chunks_tile && lane == 0) atomicSub(&open_groups[tile_idx >> 6], 1u);
+            if (t_wave_start) t_last_grab = __builtin_amdgcn_s_memrealtime();
+            LG(LG_GRAB_X, 1);
+            const uint32_t left = n_chunks_tile - u_end;
+            grab = left >= 8u * gmax ? gmax : (left >= 8u && gmax >= 2u ? 2u : 1u);
+            took_any = true;
+          }
+          const uint32_t grp = u_cur >> 2, pair = u_cur & 3u;
+          const uint32_t row = grp / n_sb, sb = grp - row * n_sb;
+          c_x0 = tile_x0 + (int)pair * 2;
+          c_y = tile_y0 + (int)row;
+          c_pix0 = (int)row * 8 + (int)pair * 2;
+          c_s0 = sample_first + (int)(sb << shift);
+          c_next = 0;
+          c_end = (c_y < height && c_x0 < width) ? unit_paths : 0;
+          continue;
+        }
+        // RT_SKY_PATHS paths per lane and iteration.  Two or three -- independent chains of primary ray -> environment lookup for
+        // the scheduler to interleave, in a loop that carries no other state -- measure the same as one (32.50 / 32.65 vs 32.55 ms:
+        // profiles/r04o_sky_ab.log): what the loop saves is the phase machine's instructions, scalar and vector, not latency.
+#ifndef RT_SKY_PATHS
+#define RT_SKY_PATHS 1
+#endif
+        LGM("sky_begin");
+        LGT0();
+        const int avail = c_end - c_next;
+        const int take = avail < 64 * RT_SKY_PATHS ? avail : 64 * RT_SKY_PATHS;
+        const int l = lane_now();
+        bool valid[RT_SKY_PATHS];
+        int  pxs[RT_SKY_PATHS];
+        rt_v3 dirs[RT_SKY_PATHS];
+        bool slow = false;
+#pragma unroll
+        for (int q = 0; q < RT_SKY_PATHS; q++) {
+          const int kq = l + 64 * q;
+          const int k = c_next + kq;
+          pxs[q] = k >> shift;
+          const int sm = c_s0 + (k & ((1 << shift) - 1));
+          const int x = c_x0 + pxs[q];
+          valid[q] = kq < take && x < width && sm < sample_end;
+          rt_v3 o = rt_v3_make(0, 0, 0);
+          dirs[q] = rt_v3_make(0, 0, 1);
+          Ray3 r;
+          if (valid[q]) primary_ray(PP, x, c_y, sm, o, dirs[q]);
+          ray_setup<SHORT_DIV>(r, o, dirs[q]);
+          slow = slow || (valid[q] && !r.fast);
+        }
+        if (__ballot(slow) != 0ull) break;          // the general loop redoes this batch, and the rest of the tile
+        uint32_t nv = 0;
+#pragma unroll
+        for (int q = 0; q < RT_SKY_PATHS; q++) {
+          if (valid[q]) {
+            const rt_v3 bg = background_lookup(SP, dirs[q]);
+            const rt_v3 radiance = rt_v3_mul_add(bg, rt_v3_make(1, 1, 1), rt_v3_make(0, 0, 0));      // tint 1, emission 0 (raytracer.c:554)
+            unsigned long long *ap = reinterpret_cast<unsigned long long *>(lds_at(smem, acc_off) + (c_pix0 + pxs[q]) * 6);
+            atomicAdd(ap + 0, accum_quantize_dev(radiance.x));
+            atomicAdd(ap + 1, accum_quantize_dev(radiance.y));
+            atomicAdd(ap + 2, accum_quantize_dev(radiance.z));
+          }
+          nv += (uint32_t)__popcll(__ballot(valid[q]));
+        }
+        w_paths += nv; w_rays += nv; w_nodes += nv; w_bgs += nv;      // (the skipped root visit counts, as in the general loop)
+        LG(LG_SKY_X, 1); LG(LG_SKY_L, nv);
+        c_next += take;
+        LGT1(LG_CYC_SKY);
+        LGM("sky_end");
+      }
+    }
+#endif
+
     for (;;) {
       // ================= S: shade the hits, environment for the misses, start new paths =================
       {

@@ -24,7 +24,7 @@ LG_NAMES = ["S_ITER", "ENV_X", "ENV_L", "SHADE_X", "SHADE_L", "PSTORE_X", "PSTOR
             "NFULL_X", "NFULL_L", "NFULL_CAM", "NGLOB_X", "NGLOB_L", "NEXACT_X", "NEXACT_L", "CULLMASK_X", "PYRCHK_X", "NODE_WAIT_L",
             "NFEW0_X", "NFEW1_X", "NFEW2_X", "NFEW3_X", "NFEW4_X", "NFEW0_L", "NFEW1_L", "NFEW2_L", "NFEW3_L", "NFEW4_L",
             "LEAF_X", "LEAF_L", "LEAF_CAM", "POP_X", "POP_L", "POP_UP_L", "POP_RETEST_L", "POP_CAM", "POP_UP_X", "POP_RETEST_X", "POP_DONE_L",
-            "CYC_S", "CYC_NODE", "CYC_LEAF", "CYC_POP", "CYC_WAVE", "CYC_TILE"]
+            "CYC_S", "CYC_NODE", "CYC_LEAF", "CYC_POP", "CYC_WAVE", "CYC_TILE", "SKY_X", "SKY_L", "CYC_SKY"]
 
 # (config, shader, width, height, spp, bounces): a spread of block mixes -- no nodes at all (quad), environment-dominated
 # (tower), deep bounce chains (helmet at 16 bounces), primary rays only (1 bounce, debug shader), small frames whose launch

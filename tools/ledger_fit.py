@@ -37,6 +37,7 @@ def _node_any(c):
 
 
 BLOCKS = [
+    ("SKY_X", "sky loop: a batch of up to 64 camera paths of a tile whose pyramid misses the root (primary ray, fast flag, environment, accumulate)", "SKY_X", "SKY_L", 648, 0.85, 1.15),
     ("S_ITER", "S block: entry, park decision, counters, exit into the traversal loop", "S_ITER", None, None, 20, 400),
     ("ENV_X", "S: environment lookup of the misses (atan2, asin, bilinear fetch, 3 x pow)", "ENV_X", "ENV_L", 383, 0.9, 1.1),
     ("SHADE_T", "S: shade_hit, Disney material with 4 textures (helmet)", _disney_tex, "SHADE_L", 1776, 0.75, 1.05),
@@ -147,7 +148,7 @@ def main(tag, out):
     # groups
     grp = collections.OrderedDict()
     for (key, *_), r in zip(BLOCKS, rows):
-        g = ("S block: environment" if key == "ENV_X" else "S block: shading (+ parking)" if key in ("SHADE_T", "SHADE_P", "SHADE_D", "PSTORE_X", "PLOAD_X") else
+        g = ("sky loop (tiles that miss the root)" if key == "SKY_X" else "S block: environment" if key == "ENV_X" else "S block: shading (+ parking)" if key in ("SHADE_T", "SHADE_P", "SHADE_D", "PSTORE_X", "PLOAD_X") else
              "S block: regeneration, primary rays, ray set-up, accumulate, glue" if key in ("S_ITER", "ACCUM_X", "REGEN_X", "PRIM_X", "START_X", "GRAB_X") else
              "NODE blocks (full)" if key in ("NFULL_X", "NGLOB_X") else "NODE blocks (culled) + cull masks + candidate check" if key.startswith(("NFEW", "CULL", "PYR")) else
              "NODE glue" if key == "NODE_ANY" else "LEAF blocks" if key == "LEAF_X" else "pop loops" if key.startswith("POP") else
@@ -170,10 +171,13 @@ def main(tag, out):
         CL, tot = cy["ledger"], cy["ledger"]["CYC_WAVE"]
         named = [("S blocks (environment, shading, regeneration, ray set-up)", "CYC_S"), ("NODE blocks", "CYC_NODE"), ("LEAF blocks", "CYC_LEAF"),
                  ("pop loops", "CYC_POP"), ("tile set-up, joins", "CYC_TILE")]
+        if CL.get("CYC_SKY"):
+            named.insert(0, ("sky loop (tiles that miss the root)", "CYC_SKY"))
         lines += ["## Shader-clock cycles per kind of block (`-DRT_LEDGER=2`: `s_memtime` around the blocks, summed over the 4 096 waves)", "",
                   f"(That build runs the frame in {cy['kernel_ms']:.1f} ms -- the timers and counters perturb it; the SHARES are what it is for.)", "",
                   "| kind | share of the waves' cycles | share of the VALU wave-instructions (table above) |", "|---|---|---|"]
         inst_share = {"CYC_S": sum(v for g, v in grp.items() if g.startswith("S block")) / total,
+                      "CYC_SKY": grp.get("sky loop (tiles that miss the root)", 0.0) / total,
                       "CYC_NODE": sum(v for g, v in grp.items() if g.startswith("NODE")) / total,
                       "CYC_LEAF": grp.get("LEAF blocks", 0.0) / total, "CYC_POP": grp.get("pop loops", 0.0) / total,
                       "CYC_TILE": grp.get("tiles, joins", 0.0) / total}
