@@ -60,13 +60,6 @@ static void *vec_push(Vec *v, size_t elem) {
 
 static bool load_rgb8(char const *p, Image *img, Err *e);
 
-/* texels of image k of a model: `<model>.image<k>.rgb8` (rt_model.h) */
-static bool load_side_image(char const *model_path, int k, Image *img, Err *e) {
-  char p[4096];
-  snprintf(p, sizeof p, "%s.image%d.rgb8", model_path, k);
-  return load_rgb8(p, img, e);
-}
-
 bool rt_model_load_rgb8(char const *path, Image *out, char *err, size_t err_len) {
   Err e = { err, err_len };
   return load_rgb8(path, out, &e);
@@ -600,6 +593,42 @@ static int texture_source(Gltf const *g, J_Value const *ref) {        /* {"index
   return j_int(j_get(tex, "source"), -1);
 }
 
+/* image `im` of a glTF file: the RT8I side file when there is one (any codec, written by tools/extract_textures.py), else the
+ * embedded or referenced stream itself when it is a baseline JPEG (rt_jpeg.c: the bytes PIL hands the Python loader) */
+static bool load_gltf_image(Gltf const *g, char const *path, int im, Image *img, Err *e) {
+  char p[4096];
+  snprintf(p, sizeof p, "%s.image%d.rgb8", path, im);
+  FILE *side = fopen(p, "rb");
+  if (side) { fclose(side); return load_rgb8(p, img, e); }
+  J_Value *ji = j_at(j_get(g->js, "images"), im);
+  J_Value *bvr = j_get(ji, "bufferView"), *uri = j_get(ji, "uri");
+  byte const *bytes = NULL;
+  byte *owned = NULL;
+  size_t n = 0;
+  if (bvr) {
+    J_Value *bv = j_at(j_get(g->js, "bufferViews"), j_int(bvr, -1));
+    int b = j_int(j_get(bv, "buffer"), -1);
+    size_t off = (size_t)j_num(j_get(bv, "byteOffset"), 0), len = (size_t)j_num(j_get(bv, "byteLength"), 0);
+    if (!bv || b < 0 || b >= g->n_buffers || off + len > g->buffers[b].len) return fail(e, "image %d: bad bufferView", im);
+    bytes = g->buffers[b].data + off;
+    n = len;
+  } else if (uri && uri->kind == J_STR && strncmp(uri->str, "data:", 5) != 0) {
+    char base[4096], full[8300];
+    dir_of(path, base, sizeof base);
+    snprintf(full, sizeof full, "%s%s", base, uri->str);
+    owned = read_file(full, &n);
+    if (!owned) return fail(e, "image %d: cannot read '%s'", im, full);
+    bytes = owned;
+  } else {
+    return fail(e, "image %d: no side file '%s' and no bufferView / file uri to decode", im, p);
+  }
+  char msg[200] = "";
+  bool ok = rt_jpeg_decode(bytes, n, img, msg, sizeof msg);
+  free(owned);
+  if (!ok) return fail(e, "image %d: %s; write '%s' with tools/extract_textures.py instead", im, msg, p);
+  return true;
+}
+
 static bool load_gltf(char const *path, RT_Model *out, Err *e) {
   Gltf g;
   memset(&g, 0, sizeof g);
@@ -610,7 +639,7 @@ static bool load_gltf(char const *path, RT_Model *out, Err *e) {
   bool *seen = NULL;
   if (!ok) goto done;
 
-  /* images: side files, in the order of the "images" array */
+  /* images, in the order of the "images" array; loaded when a material uses them (load_gltf_image) */
   out->n_images = j_len(j_get(g.js, "images"));
   out->images = calloc((size_t)(out->n_images > 0 ? out->n_images : 1), sizeof *out->images);
   bool *image_loaded = calloc((size_t)(out->n_images > 0 ? out->n_images : 1), sizeof(bool));
@@ -641,7 +670,7 @@ static bool load_gltf(char const *path, RT_Model *out, Err *e) {
       int im = tex_of[k];
       if (im < 0) continue;
       if (im >= out->n_images) { ok = fail(e, "material %d refers to image %d of %d", i, im, (int)out->n_images); break; }
-      if (!image_loaded[im]) { ok = load_side_image(path, im, &out->images[im], e); image_loaded[im] = ok; }
+      if (!image_loaded[im]) { ok = load_gltf_image(&g, path, im, &out->images[im], e); image_loaded[im] = ok; }
       *slots[k] = &out->images[im];
     }
     out->materials[i] = d;

@@ -2,9 +2,11 @@
  * stb_image (none of which are in the reference tree).  `.obj` (+ `.mtl`) and `.glb` / `.gltf` files become the
  * Triangle[] + PBR_Shader_Data[] + Image[] (+ Camera) that scene_init() and render_thread_proc() consume.
  *
- * No image decoder is linked: the texels of image k of a model come from the side file `<model path>.image<k>.rgb8`
- * (16-byte header "RT8I", i32 width, height, components, then the rows; tools/extract_textures.py writes them from
- * the JPEG / PNG data with PIL).  A material that references an image whose side file is missing fails the load.
+ * Texels of image k of a model: the side file `<model path>.image<k>.rgb8` when it exists (16-byte header "RT8I", i32
+ * width, height, components, then the rows; tools/extract_textures.py writes them from any codec PIL reads), else the
+ * stream the glTF file embeds or names, decoded by rt_jpeg.c when it is a baseline JPEG (helmet.glb's four images):
+ * libjpeg's default arithmetic restated, so both routes give the same bytes.  A material that references an image
+ * neither route can produce fails the load with a message.
  *
  * Semantics follow raytracing_c_amd/loaders.py (the loader the benchmark configs use) field for field: material
  * defaults of driver.c:549-568 (OBJ) and :628-639 (glTF, with the glTF-spec defaults metallic = roughness = 1 where
@@ -42,5 +44,9 @@ Camera rt_model_camera(f32 const translation[3], f32 const rotation[4], f32 yfov
 
 /* one RT8I side file (what image k of a model is read from) -> Image; used for the environment map too */
 bool rt_model_load_rgb8(char const *path, Image *out, char *err, size_t err_len);
+
+/* rt_jpeg.c: a baseline JPEG stream (what helmet.glb embeds) -> RGB8 Image with libjpeg's default arithmetic (islow IDCT,
+ * fancy upsampling), i.e. the texels the Python loader gets from PIL; pixels.data is malloc'ed.  false + message otherwise. */
+bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, size_t err_len);
 
 #endif /* RT_MODEL_H */

@@ -1,6 +1,7 @@
 """examples/rt_model.c: model loading in C for a host of librt_hip.so (driver.c:510-728 does it with
 codin's obj.h / gltf.h / stb_image, which are not in the reference tree).  Textures come from RT8I side files
-(tools/extract_textures.py), so no image decoder is linked.
+(tools/extract_textures.py) when they exist, else from the baseline JPEG streams the model embeds (examples/rt_jpeg.c, which
+restates libjpeg's default arithmetic: the same bytes PIL gives the Python loader).
 
 The C loader is checked against the Python loader the benchmark configs use (same triangles, normals, uvs, materials,
 texture assignment, camera), and -- on the GPU -- through examples/driver_min: a C host that takes a MODEL PATH like
@@ -124,22 +125,92 @@ def test_c_loader_fails_loudly(tmp_path):
     err = C.create_string_buffer(512)
     assert not lib.rt_model_load(str(tmp_path / "nothing.obj").encode(), C.byref(m), err, 512) and b"cannot read" in err.value
     assert not lib.rt_model_load(b"model.fbx", C.byref(m), err, 512) and b"Unrecognized file type" in err.value     # driver.c:724-727
-    link = tmp_path / "helmet.glb"                            # textures referenced, side files missing
+    blob = bytearray(open(os.path.join(ASSETS, "helmet.glb"), "rb").read())   # a codec rt_jpeg.c does not read, no side files
+    at = blob.index(b"\xff\xc0\x00\x11\x08")                 # SOF0 of the first embedded image -> SOF2 (progressive)
+    blob[at + 1] = 0xC2
+    bad = tmp_path / "helmet_progressive.glb"
+    bad.write_bytes(bytes(blob))
+    assert not lib.rt_model_load(str(bad).encode(), C.byref(m), err, 512)
+    assert b"progressive" in err.value and b"extract_textures" in err.value
+
+
+def _jpeg_decode(lib, data):
+    from raytracing_c_amd import ctypes_abi as abi
+    lib.rt_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(abi.Image), C.c_char_p, C.c_size_t]
+    lib.rt_jpeg_decode.restype = C.c_bool
+    img = abi.Image()
+    err = C.create_string_buffer(256)
+    if not lib.rt_jpeg_decode(data, len(data), C.byref(img), err, 256):
+        return None, err.value.decode()
+    a = np.frombuffer(C.string_at(img.pixels.data, img.pixels.len), np.uint8).reshape(img.height, img.width, 3).copy()
+    C.CDLL(None).free(C.c_void_p(img.pixels.data))
+    return a, ""
+
+
+@pytest.mark.parametrize("size", [(64, 64), (33, 17), (1, 1), (2, 3), (4, 5), (3, 8), (5, 2), (6, 6), (100, 75), (17, 33), (250, 129)])
+def test_rt_jpeg_is_libjpeg_bit_for_bit(size):
+    """examples/rt_jpeg.c against PIL (libjpeg-turbo, default islow IDCT + fancy upsampling): every subsampling PIL writes,
+    odd sizes (edge replication of the chroma planes), restart intervals, optimised Huffman tables, grayscale."""
+    import io
+    from PIL import Image as PI
+    lib, _ = _lib()
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    im = PI.fromarray(rng.integers(0, 256, (h // 4 + 1, w // 4 + 1, 3), dtype=np.uint8)).resize((w, h), PI.BILINEAR)
+    noisy = PI.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    cases = [(src, dict(quality=q, subsampling=sub)) for src in (im, noisy) for sub in (0, 1, 2) for q in (30, 95)]
+    cases += [(im.convert("L"), dict(quality=80)), (im, dict(quality=80, restart_marker_blocks=1)),
+              (noisy, dict(quality=60, restart_marker_rows=1, subsampling=2)), (im, dict(quality=85, optimize=True))]
+    for src, kw in cases:
+        bio = io.BytesIO()
+        src.save(bio, "JPEG", **kw)
+        data = bio.getvalue()
+        if "restart_marker_blocks" in kw or "restart_marker_rows" in kw:
+            assert b"\xff\xdd" in data
+        got, msg = _jpeg_decode(lib, data)
+        assert got is not None, (kw, msg)
+        assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(data)).convert("RGB"))), kw
+    bio = io.BytesIO()
+    im.save(bio, "JPEG", progressive=True)
+    got, msg = _jpeg_decode(lib, bio.getvalue())
+    assert got is None and "progressive" in msg
+    got, msg = _jpeg_decode(lib, b"\x89PNG\r\n\x1a\n" + bytes(64))
+    assert got is None and "not a JPEG" in msg
+    got, msg = _jpeg_decode(lib, data[: len(data) // 3])              # truncated entropy-coded data: zeros are fed, no crash
+    assert got is None or got.shape == (h, w, 3)
+
+
+def test_c_loader_decodes_the_embedded_jpegs_of_the_helmet(tmp_path):
+    """No preparation step: helmet.glb by itself (four 2048 x 2048 baseline 4:2:0 JPEGs) -> the texels the Python loader gets."""
+    from raytracing_c_amd.loaders import load_model_data
+    link = tmp_path / "helmet.glb"
     os.symlink(os.path.join(ASSETS, "helmet.glb"), link)
-    assert not lib.rt_model_load(str(link).encode(), C.byref(m), err, 512) and b"side file" in err.value
+    c = _load_c(str(link))
+    p = load_model_data(os.path.join(ASSETS, "helmet.glb"))
+    used = {t for m in p["materials"] for t in (m.texture_albedo, m.texture_normal, m.texture_metal_roughness, m.texture_emission)
+            if t is not None}
+    assert len(used) == 4
+    for k in used:
+        assert np.array_equal(c["images"][k], p["images"][k]), k
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("asset,camera", [("helmet.glb", None), ("spheres.glb", None), ("tower.obj", "0 12.5 32 0 0 0 1 1.2217305")])
-def test_c_driver_takes_a_model_path(tmp_path, oracle, asset, camera):
+@pytest.mark.parametrize("asset,camera,side_files", [("helmet.glb", None, True), ("helmet.glb", None, False), ("spheres.glb", None, True),
+                                                     ("tower.obj", "0 12.5 32 0 0 0 1 1.2217305", True)])
+def test_c_driver_takes_a_model_path(tmp_path, oracle, asset, camera, side_files):
     """driver_min MODEL ... : load with rt_model.c, scene_init, render_thread_proc threads, PPM -- byte-equal to the oracle's
-    render of the same C-loaded scene (camera of the file, or the override the tower config needs)."""
+    render of the same C-loaded scene (camera of the file, or the override the tower config needs); once from the
+    helmet's .glb alone, its JPEGs decoded in C."""
     from raytracing_c_amd.background import procedural_background
     from raytracing_c_amd.scene import build_scene
     from tests import _oracle
     from tests.test_c_driver import _read_ppm
     from tools.extract_textures import extract
     prefix = extract(os.path.join(ASSETS, asset), str(tmp_path), background=True)
+    if not side_files:                                        # the .glb alone: rt_jpeg.c decodes what it embeds
+        import glob
+        for f in glob.glob(prefix + ".image*.rgb8"):
+            os.remove(f)
     out = str(tmp_path / "o.ppm")
     w, h, s, b = 96, 54, 4, 6
     cmd = [os.path.join(EX, "driver_min"), prefix, str(w), str(h), str(s), str(b), "3", out, "--background", prefix + ".background.rgb8"]
