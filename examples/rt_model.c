@@ -144,6 +144,14 @@ static PBR_Shader_Data material_default(f32 r, f32 g, f32 b, f32 roughness, f32 
   return m;
 }
 
+/* an encoded image (what stb_image_load_bytes takes in driver.c:106-116) -> RGB8: baseline JPEG (rt_jpeg.c) or PNG (rt_png.c) */
+static bool decode_image(byte const *bytes, size_t n, Image *img, char *msg, size_t msg_len) {
+  if (n >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return rt_jpeg_decode(bytes, n, img, msg, msg_len);
+  if (n >= 4 && bytes[0] == 0x89 && bytes[1] == 'P' && bytes[2] == 'N' && bytes[3] == 'G') return rt_png_decode(bytes, n, img, msg, msg_len);
+  snprintf(msg, msg_len, "neither a JPEG nor a PNG stream");
+  return false;
+}
+
 /* ------------------------------------------------------------------------------------------------------------- */
 /* OBJ / MTL (loaders.py: _parse_mtl, load_obj; driver.c:510-587)                                                  */
 
@@ -152,6 +160,8 @@ typedef struct {
   f32  kd[3], ke[3];
   bool pbr, has_pr, has_pm, has_ps, has_aniso;
   f32  pr, pm, ps, aniso;
+  char maps[4][1024];              /* files of map_Kd, map_Ke, norm, map_Pm ("" = none), relative to the .mtl */
+  char base[1024];
 } Mtl;
 
 static int split_ws(char *line, char **tok, int max_tok) {
@@ -191,6 +201,7 @@ static void parse_mtl(char const *path, Vec *mtls) {
       memset(cur, 0, sizeof *cur);
       join_tokens(tok, 1, nt, cur->name, sizeof cur->name);
       cur->kd[0] = cur->kd[1] = cur->kd[2] = (f32)0.8;
+      dir_of(path, cur->base, sizeof cur->base);
       continue;
     }
     if (!cur) continue;
@@ -206,8 +217,11 @@ static void parse_mtl(char const *path, Vec *mtls) {
       else if (!strcmp(tok[0], "Ps")) { cur->ps = v; cur->has_ps = true; }
       else if (!strcmp(tok[0], "aniso")) { cur->aniso = v; cur->has_aniso = true; }
     }
-    /* map_* texture keys: the OBJ assets of the configs have none; a model that needs them goes through side files
-     * of a glTF export (texture maps of .mtl files are not wired up here) */
+    else if (nt >= 2) {                                 /* texture maps: the last token is the file (options before it are ignored) */
+      static char const *const keys[4] = { "map_Kd", "map_Ke", "norm", "map_Pm" };
+      for (int k = 0; k < 4; k++)
+        if (!strcmp(tok[0], keys[k])) snprintf(cur->maps[k], sizeof cur->maps[k], "%s", tok[nt - 1]);
+    }
   }
   free(text);
 }
@@ -276,11 +290,13 @@ static bool load_obj(char const *path, RT_Model *out, Err *e) {
 
   isize n = (isize)F.len;
   /* materials: one per MTL entry (driver.c:549-568); faces without a known material share one default */
-  bool need_default = false;
+  bool need_default = false, mat_fail = false;
   for (isize i = 0; i < n; i++) need_default |= ((int *)FM.data)[i] < 0;
   out->n_materials = (isize)mtls.len + (need_default ? 1 : 0);
   out->materials = calloc((size_t)(out->n_materials > 0 ? out->n_materials : 1), sizeof *out->materials);
-  for (size_t k = 0; k < mtls.len; k++) {
+  out->images = calloc(4 * mtls.len + 1, sizeof *out->images);      /* one per map that exists, in the order loaders.py appends them */
+  out->n_images = 0;
+  for (size_t k = 0; k < mtls.len && ok; k++) {
     Mtl const *m = &((Mtl *)mtls.data)[k];
     PBR_Shader_Data d = material_default(m->kd[0], m->kd[1], m->kd[2], 0.5f, 0.0f);
     d.emission.x = m->ke[0]; d.emission.y = m->ke[1]; d.emission.z = m->ke[2];
@@ -290,8 +306,23 @@ static bool load_obj(char const *path, RT_Model *out, Err *e) {
       d.roughness = m->has_pr ? m->pr : 0.0f;
       d.sheen = m->has_ps ? m->ps : 0.0f;
     }
+    Image **slots[4] = { &d.texture_albedo, &d.texture_emission, &d.texture_normal, &d.texture_metal_roughness };
+    for (int t = 0; t < 4 && ok; t++) {
+      if (!m->maps[t][0] || (t >= 2 && !m->pbr)) continue;          /* norm / map_Pm only count in a PBR material */
+      char full[2100], msg[200] = "";
+      snprintf(full, sizeof full, "%s%s", m->base, m->maps[t]);
+      size_t bn;
+      byte *bytes = read_file(full, &bn);
+      if (!bytes) continue;                                          /* a map that is not there is no map (loaders.py: add_image) */
+      Image *img = &out->images[out->n_images];
+      if (!decode_image(bytes, bn, img, msg, sizeof msg)) { free(bytes); ok = fail(e, "'%s': %s", full, msg); mat_fail = true; break; }
+      free(bytes);
+      out->n_images++;
+      *slots[t] = img;
+    }
     out->materials[k] = d;
   }
+  if (mat_fail) { free(V.data); free(VT.data); free(VN.data); free(F.data); free(FM.data); free(mtls.data); return false; }
   if (need_default) out->materials[mtls.len] = material_default((f32)0.8, (f32)0.8, (f32)0.8, 0.5f, 0.0f);
 
   out->n_triangles = n;
@@ -594,7 +625,7 @@ static int texture_source(Gltf const *g, J_Value const *ref) {        /* {"index
 }
 
 /* image `im` of a glTF file: the RT8I side file when there is one (any codec, written by tools/extract_textures.py), else the
- * embedded or referenced stream itself when it is a baseline JPEG (rt_jpeg.c: the bytes PIL hands the Python loader) */
+ * embedded or referenced stream itself: baseline JPEG (rt_jpeg.c) or PNG (rt_png.c), the bytes PIL hands the Python loader */
 static bool load_gltf_image(Gltf const *g, char const *path, int im, Image *img, Err *e) {
   char p[4096];
   snprintf(p, sizeof p, "%s.image%d.rgb8", path, im);
@@ -623,7 +654,7 @@ static bool load_gltf_image(Gltf const *g, char const *path, int im, Image *img,
     return fail(e, "image %d: no side file '%s' and no bufferView / file uri to decode", im, p);
   }
   char msg[200] = "";
-  bool ok = rt_jpeg_decode(bytes, n, img, msg, sizeof msg);
+  bool ok = decode_image(bytes, n, img, msg, sizeof msg);
   free(owned);
   if (!ok) return fail(e, "image %d: %s; write '%s' with tools/extract_textures.py instead", im, msg, p);
   return true;

@@ -1,7 +1,7 @@
 """examples/rt_model.c: model loading in C for a host of librt_hip.so (driver.c:510-728 does it with
 codin's obj.h / gltf.h / stb_image, which are not in the reference tree).  Textures come from RT8I side files
-(tools/extract_textures.py) when they exist, else from the baseline JPEG streams the model embeds (examples/rt_jpeg.c, which
-restates libjpeg's default arithmetic: the same bytes PIL gives the Python loader).
+(tools/extract_textures.py) when they exist, else from the streams the model embeds or names: baseline JPEG (examples/rt_jpeg.c,
+which restates libjpeg's default arithmetic: the same bytes PIL gives the Python loader) or PNG (examples/rt_png.c).
 
 The C loader is checked against the Python loader the benchmark configs use (same triangles, normals, uvs, materials,
 texture assignment, camera), and -- on the GPU -- through examples/driver_min: a C host that takes a MODEL PATH like
@@ -178,6 +178,143 @@ def test_rt_jpeg_is_libjpeg_bit_for_bit(size):
     assert got is None and "not a JPEG" in msg
     got, msg = _jpeg_decode(lib, data[: len(data) // 3])              # truncated entropy-coded data: zeros are fed, no crash
     assert got is None or got.shape == (h, w, 3)
+
+
+def _image_decode(lib, data, which):
+    from raytracing_c_amd import ctypes_abi as abi
+    fn = getattr(lib, which)
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(abi.Image), C.c_char_p, C.c_size_t]
+    fn.restype = C.c_bool
+    img = abi.Image()
+    err = C.create_string_buffer(256)
+    if not fn(data, len(data), C.byref(img), err, 256):
+        return None, err.value.decode()
+    a = np.frombuffer(C.string_at(img.pixels.data, img.pixels.len), np.uint8).reshape(img.height, img.width, 3).copy()
+    C.CDLL(None).free(C.c_void_p(img.pixels.data))
+    return a, ""
+
+
+def _raw_png(w, h, depth, ctype, rows, plte=None, interlace=0):
+    """A PNG written by hand (filter 0 rows, zlib level 6) for the formats PIL does not write."""
+    import struct
+    import zlib
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+    if plte is not None:
+        out += chunk(b"PLTE", plte)
+    raw = b"".join(b"\0" + r for r in rows)
+    cut = len(raw) // 2                                          # two IDAT chunks: the stream may be split anywhere
+    z = zlib.compress(raw)
+    return out + chunk(b"IDAT", z[:cut]) + chunk(b"IDAT", z[cut:]) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (64, 64), (33, 17), (257, 100)])
+def test_rt_png_gives_what_pil_gives(size):
+    """examples/rt_png.c against PIL's .convert("RGB"): every mode PIL writes (1, L, LA, P at 1 / 2 / 4 / 8 bits, RGB, RGBA), stored /
+    fixed / dynamic deflate blocks, all five filters (PIL picks per row), plus hand-written streams of the formats PIL only reads."""
+    import io
+    from PIL import Image as PI
+    lib, _ = _lib()
+    w, h = size
+    rng = np.random.default_rng(w * 977 + h)
+    smooth = np.asarray(PI.fromarray(rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 4), dtype=np.uint8)).resize((w, h), PI.BICUBIC))
+    noisy = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    for arr in (smooth, noisy):
+        rgb = PI.fromarray(arr[..., :3].copy(), "RGB")
+        srcs = [PI.fromarray(arr, "RGBA"), rgb, PI.fromarray(arr[..., 0].copy(), "L"), PI.fromarray(arr[..., :2].copy(), "LA"),
+                rgb.quantize(200), rgb.quantize(13), rgb.quantize(3), rgb.quantize(2), PI.fromarray(arr[..., 0].copy(), "L").convert("1")]
+        for im in srcs:
+            for kw in (dict(compress_level=0), dict(compress_level=1), dict(compress_level=9), dict(optimize=True)):
+                bio = io.BytesIO()
+                im.save(bio, "PNG", **kw)
+                got, msg = _image_decode(lib, bio.getvalue(), "rt_png_decode")
+                assert got is not None, (im.mode, kw, msg)
+                assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(bio.getvalue())).convert("RGB"))), (im.mode, kw)
+    for depth, ctype, ch in [(2, 0, 1), (4, 0, 1), (1, 0, 1), (16, 2, 3), (16, 6, 4), (16, 4, 2), (8, 4, 2), (4, 3, 1), (2, 3, 1)]:
+        rows = [bytes(rng.integers(0, 256, (w * ch * depth + 7) // 8, dtype=np.uint8)) for _ in range(h)]
+        plte = bytes(rng.integers(0, 256, 3 * 3, dtype=np.uint8)) if ctype == 3 else None        # a SHORT palette: black beyond it
+        data = _raw_png(w, h, depth, ctype, rows, plte)
+        got, msg = _image_decode(lib, data, "rt_png_decode")
+        assert got is not None, (depth, ctype, msg)
+        assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(data)).convert("RGB"))), (depth, ctype)
+    rows = [bytes(2 * w) for _ in range(h)]
+    for data, word in ((_raw_png(w, h, 16, 0, rows), "16-bit grayscale"), (_raw_png(w, h, 8, 0, rows, interlace=1), "interlaced"),
+                       (b"\xff\xd8\xff\xe0" + bytes(32), "not a PNG"), (_raw_png(w, h + 1, 8, 0, [bytes(w)] * h), "zlib stream")):
+        got, msg = _image_decode(lib, data, "rt_png_decode")
+        assert got is None and word in msg, (word, msg)
+    good = _raw_png(w, h, 8, 2, [bytes(rng.integers(0, 256, 3 * w, dtype=np.uint8)) for _ in range(h)])
+    for cut in (20, 40, len(good) // 2, len(good) - 13):                  # truncated anywhere: a message, not a crash
+        got, msg = _image_decode(lib, good[:cut], "rt_png_decode")
+        assert got is None and msg
+
+
+def test_c_loader_reads_the_texture_maps_of_an_mtl(tmp_path):
+    """map_Kd / map_Ke / norm / map_Pm of a .mtl (driver.c:549-568 loads them through stb_image): PNG and JPEG files next to the .mtl,
+    decoded in C, in the order and with the assignment of the Python loader; a map that is not there is no map."""
+    from PIL import Image as PI
+    from raytracing_c_amd.loaders import load_model_data
+    rng = np.random.default_rng(5)
+    obj = open(os.path.join(ASSETS, "quad.obj")).read()
+    (tmp_path / "q.obj").write_text(obj.replace("quad.mtl", "q.mtl").replace("usemtl Material", "usemtl A", 1)
+                                    .replace("f 1/1/1 3/4/1 4/2/1", "usemtl B\nf 1/1/1 3/4/1 4/2/1"))
+    (tmp_path / "q.mtl").write_text("newmtl A\nKd 0.5 0.6 0.7\nmap_Kd -s 1 1 1 kd.png\nmap_Ke ke.jpg\nnorm missing.png\n"
+                                    "newmtl B\nKd 1 1 1\nPr 0.3\nPm 0.9\nmap_Kd kd.png\nnorm n.png\nmap_Pm pm.jpg\nmap_Ke nothing.png\n")
+    PI.fromarray(rng.integers(0, 256, (16, 24, 4), dtype=np.uint8), "RGBA").save(tmp_path / "kd.png")
+    PI.fromarray(rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)).resize((40, 24), PI.BILINEAR).save(tmp_path / "ke.jpg", quality=90)
+    PI.fromarray(rng.integers(0, 256, (9, 5), dtype=np.uint8), "L").save(tmp_path / "n.png")
+    PI.fromarray(rng.integers(0, 256, (4, 4, 3), dtype=np.uint8)).resize((17, 33), PI.BICUBIC).save(tmp_path / "pm.jpg", subsampling=1)
+    c = _load_c(str(tmp_path / "q.obj"))
+    p = load_model_data(str(tmp_path / "q.obj"))
+    assert len(p["images"]) == 5 and len(c["images"]) == 5          # A: kd, ke; B: kd, n, pm (norm of the non-PBR material A does not count)
+    for a, b in zip(c["images"], p["images"]):
+        assert np.array_equal(a, b)
+    for mc, mp in zip(c["materials"], p["materials"]):
+        for f in ("texture_albedo", "texture_normal", "texture_metal_roughness", "texture_emission"):
+            assert getattr(mc, f) == getattr(mp, f), f
+    assert np.array_equal(c["material_ids"], p["material_ids"])
+    (tmp_path / "kd.png").write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(40))             # a map that is there but broken: loud
+    lib, RT_Model = _lib()
+    m = RT_Model()
+    err = C.create_string_buffer(512)
+    assert not lib.rt_model_load(str(tmp_path / "q.obj").encode(), C.byref(m), err, 512) and b"kd.png" in err.value
+
+
+def test_c_loader_decodes_png_images_of_a_gltf(tmp_path):
+    """A .gltf whose material names a PNG by uri and another embedded in the buffer: the C loader's texels == the Python loader's."""
+    import io
+    import json
+    from PIL import Image as PI
+    from raytracing_c_amd.loaders import load_model_data
+    rng = np.random.default_rng(9)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    uv = np.array([[0, 0], [1, 0], [0, 1]], np.float32)
+    bio = io.BytesIO()
+    PI.fromarray(rng.integers(0, 256, (12, 20, 3), dtype=np.uint8)).quantize(40).save(bio, "PNG")
+    emb = bio.getvalue()
+    blob = pos.tobytes() + uv.tobytes() + emb
+    (tmp_path / "t.bin").write_bytes(blob)
+    PI.fromarray(rng.integers(0, 256, (31, 15, 4), dtype=np.uint8), "RGBA").save(tmp_path / "base.png")
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "material": 0}]}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}, "emissiveTexture": {"index": 1}, "emissiveFactor": [1, 1, 1]}],
+           "textures": [{"source": 0}, {"source": 1}],
+           "images": [{"uri": "base.png"}, {"bufferView": 2, "mimeType": "image/png"}],
+           "buffers": [{"uri": "t.bin", "byteLength": len(blob)}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24},
+                           {"buffer": 0, "byteOffset": 60, "byteLength": len(emb)}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3", "min": [0, 0, 0], "max": [1, 1, 0]},
+                         {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"}]}
+    (tmp_path / "t.gltf").write_text(json.dumps(doc))
+    c = _load_c(str(tmp_path / "t.gltf"))
+    p = load_model_data(str(tmp_path / "t.gltf"))
+    assert len(p["images"]) == 2
+    for k in range(2):
+        assert np.array_equal(c["images"][k], p["images"][k]), k
+    assert c["materials"][0].texture_albedo == p["materials"][0].texture_albedo == 0
+    assert c["materials"][0].texture_emission == p["materials"][0].texture_emission == 1
 
 
 def test_c_loader_decodes_the_embedded_jpegs_of_the_helmet(tmp_path):
