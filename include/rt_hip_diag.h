@@ -51,8 +51,9 @@ extern int rt_get_wave_times(u64 *out, i32 max_waves);
 extern int rt_test_math(i32 op, i32 n, f32 const *x, f32 const *y, f32 *out);
 /* the leaf blocks' four-instruction reciprocal against IEEE 1.0f / x over all 2^32 bit patterns: out[0] differing patterns
  * inside its domain (0 expected), out[1] patterns outside the domain, out[2] differing ones among those, out[3] first
- * differing pattern inside the domain + 1 */
-extern int rt_test_rcp_sweep(u64 out[4]);
+ * differing pattern inside the domain + 1; the form without the fix-up that the leaf blocks use (rcp_leaf): out[4] finite non-zero
+ * patterns below 2^102 that differ (0 expected), out[5] patterns 0 / infinity / NaN whose result is not NaN (0 expected) */
+extern int rt_test_rcp_sweep(u64 out[6]);
 /* the kernels' sRGB decode of a texture sample against rt_srgb_to_linear1() for every float in [0, 2] (and 4 M negative ones):
  * out[0] patterns compared, out[1] differing (0 expected), out[2] first differing pattern + 1 */
 extern int rt_test_srgb_sweep(u64 out[3]);

@@ -2461,8 +2461,8 @@ static int run_sweep(int (*launch)(unsigned long long *, hipStream_t), const cha
 
 // rcp_exact() (the six-instruction reciprocal of the leaf blocks) against the IEEE quotient over all 2^32 bit patterns:
 // out[0] differing patterns inside its domain (must be 0), out[1] patterns outside the domain, out[2] differing ones
-// among those, out[3] first differing pattern inside the domain + 1.
-extern "C" int rt_test_rcp_sweep(u64 out[4]) { return run_sweep(rt_launch_test_rcp_sweep, "rt_test_rcp_sweep", out, 4); }
+// among those, out[3] first differing pattern inside the domain + 1; out[4], out[5]: the same for rcp_leaf() (rt_hip_diag.h).
+extern "C" int rt_test_rcp_sweep(u64 out[6]) { return run_sweep(rt_launch_test_rcp_sweep, "rt_test_rcp_sweep", out, 6); }
 
 // The kernels' sRGB decode of a texture sample (division by 1.055 as a corrected multiplication) against
 // rt_srgb_to_linear1() for every float in [0, 2] (and 4 M negative ones): out[0] patterns compared, out[1] differing (0 expected),

@@ -315,6 +315,22 @@ __device__ __forceinline__ float rcp_exact(float x) {
   float z = __builtin_fmaf(e, y, y);
   return __builtin_amdgcn_div_fixupf(z, xs, 1.0f) * 0x1p24f;
 }
+// rcp_exact() without the v_div_fixup_f32, for the leaf blocks only: equal to 1.0f / x for every finite non-zero |x| < 2^102
+// (the fix-up passes those through); NaN instead of +-infinity for x = +-0 and instead of +-0 for x = +-infinity.  A
+// determinant of zero or infinity is no hit either way -- with inv_det = infinity u, v, t are infinite or NaN: an infinite
+// u, v or t fails one of the five comparisons or is not below `best`, a NaN t is not below `best`; with inv_det = 0 the
+// distance is 0 < epsilon; with NaN everything is NaN and t < best is false -- so ray_triangles_hit_8's outcome is the same.
+__device__ __forceinline__ float rcp_leaf(float x) {
+#ifdef RT_LEAF_SANITISE
+  return rcp_exact(x);
+#else
+  float xs = x * 0x1p24f;
+  float y = __builtin_amdgcn_rcpf(xs);
+  float e = __builtin_fmaf(-xs, y, 1.0f);
+  float z = __builtin_fmaf(e, y, y);
+  return z * 0x1p24f;
+#endif
+}
 __device__ __forceinline__ bool rcp_exact_outside(float x) {
   return __builtin_fabsf(x) >= RT_SHORT_DIV_MAX_X && __builtin_fabsf(x) < RT_INF;
 }
@@ -380,16 +396,23 @@ __device__ __forceinline__ bool leaf_test_short_div(const RT_KParams &P, const R
       rt_v3 edge1 = rt_v3_make(bx[k], by[k], bz[k]), edge2 = rt_v3_make(cx[k], cy[k], cz[k]);
       rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
       float det = rt_v3_dot(edge1, rxe2);
-      float inv_det = rcp_exact(det);
+      float inv_det = rcp_leaf(det);
       rt_v3 s = rt_v3_sub(r.o, rt_v3_make(ax[k], ay[k], az[k]));
       rt_v3 sxe1 = rt_v3_cross(s, edge1);
       float u = inv_det * rt_v3_dot(s, rxe2);
       float v = inv_det * rt_v3_dot(r.d, sxe1);
       float t = inv_det * rt_v3_dot(edge2, sxe1);
       bool miss = (u < -RT_EPS) || (u > 1.0f + RT_EPS) || (v < -RT_EPS) || (u + v > 1.0f + RT_EPS) || (t < RT_EPS);
+#ifdef RT_LEAF_SANITISE
       float dist = miss ? RT_INF : t;
       dist = (dist > 0.0f) ? dist : RT_INF;          // NaN -> +inf (min_f32x8)
       if (dist < best) { best = dist; bi = h * 4 + k; bu = u; bv = v; }   // lowest lane wins ties
+#else
+      // min_f32x8's sanitising (lanes <= epsilon or NaN -> +inf, raytracer.c:15-32) folded into the comparison: a triangle
+      // that is not a miss has t >= epsilon or t NaN, `best` is never NaN, and NaN < best is false like +inf < best --
+      // the same triangle wins with the same t, three vector instructions fewer per triangle
+      if (!miss && t < best) { best = t; bi = h * 4 + k; bu = u; bv = v; }   // lowest lane wins ties
+#endif
     }
   }
   if (best < hit.t) {

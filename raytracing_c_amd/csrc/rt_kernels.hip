@@ -1023,9 +1023,11 @@ __global__ void rt_test_math_kernel(int op, int n, const float *x, const float *
 // All 2^32 bit patterns x: rcp_exact(x) against the IEEE quotient 1.0f / x.  counts[0] = patterns inside the claimed
 // domain (|x| < 2^102, infinity, NaN) that differ (NaN equals NaN), counts[1] = patterns outside it, counts[2] = of those,
 // how many differ (why the domain ends there), counts[3] = first differing pattern inside the domain + 1.
+// rcp_leaf(x), the leaf blocks' form without the fix-up: counts[4] = finite non-zero patterns with |x| < 2^102 that differ from
+// 1.0f / x, counts[5] = patterns x = +-0, +-infinity, NaN for which it is NOT NaN (what the leaf blocks' argument rests on).
 __global__ void rt_test_rcp_sweep_kernel(unsigned long long *counts) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t bad_in = 0, n_out = 0, bad_out = 0, first = 0;
+  uint32_t bad_in = 0, n_out = 0, bad_out = 0, first = 0, leaf_bad = 0, leaf_special = 0;
   for (uint32_t k = 0; k < 256u; k++) {
     const uint32_t b = tid * 256u + k;
     const float x = __uint_as_float(b);
@@ -1034,7 +1036,13 @@ __global__ void rt_test_rcp_sweep_kernel(unsigned long long *counts) {
     const bool same = w_nan ? g_nan : (g == w);
     if (rcp_exact_outside(x)) { n_out += 1; bad_out += same ? 0u : 1u; }
     else if (!same) { bad_in += 1; if (!first) first = b + 1u; }
+    const uint32_t l = __float_as_uint(rcp_leaf(x)), mag = b & 0x7FFFFFFFu;
+    const bool l_nan = (l & 0x7FFFFFFFu) > 0x7F800000u;
+    if (mag == 0u || mag >= 0x7F800000u) leaf_special += l_nan ? 0u : 1u;
+    else if (!rcp_exact_outside(x)) leaf_bad += (l == w) ? 0u : 1u;
   }
+  if (leaf_bad) atomicAdd(&counts[4], (unsigned long long)leaf_bad);
+  if (leaf_special) atomicAdd(&counts[5], (unsigned long long)leaf_special);
   if (bad_in) atomicAdd(&counts[0], (unsigned long long)bad_in);
   if (n_out) atomicAdd(&counts[1], (unsigned long long)n_out);
   if (bad_out) atomicAdd(&counts[2], (unsigned long long)bad_out);

@@ -67,10 +67,12 @@ def test_short_reciprocal_equals_the_division(rt, oracle, diag):
     pattern with |x| < 2^102, both infinities and every NaN is compared on the device with 1.0f / x, and a sample --
     denormals, zeros, infinities, powers of two, all-ones mantissas -- with the CPU's division (the oracle's)."""
     from tests import _oracle
-    out = (C.c_uint64 * 4)()
+    out = (C.c_uint64 * 6)()
     assert rt.diag.rt_test_rcp_sweep(out) == 0, rt.last_error(rt.diag)
-    inside_bad, outside_n, outside_bad, first = (int(v) for v in out)
+    inside_bad, outside_n, outside_bad, first, leaf_bad, leaf_special_not_nan = (int(v) for v in out)
     assert inside_bad == 0, f"first differing pattern {first - 1:#010x}"
+    # the leaf blocks' form without v_div_fixup_f32 (rcp_leaf): the quotient for every finite non-zero |x| < 2^102, NaN for 0 / inf / NaN
+    assert leaf_bad == 0 and leaf_special_not_nan == 0
     assert outside_n == 2 * 26 * (1 << 23)           # 2^102 <= |x| < infinity: exponent fields 229..254, both signs
     assert outside_bad > 0                            # ... where it really does differ: the host's bound is needed
     rng = np.random.default_rng(11)
