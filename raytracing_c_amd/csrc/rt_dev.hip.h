@@ -705,7 +705,18 @@ __device__ __forceinline__ float srgb_to_linear_tex1(float x) {
   float a = x + 0.055f;
   float q = a * c;
   float r = __builtin_fmaf(-1.055f, q, a);
+#ifdef RT_EXP_POW_PLAIN
   return rt_powf(__builtin_fmaf(r, c, q), 2.4f);
+#else
+  // rt_powf(b, 2.4f) (rt_math.h) straight-line: its clamp of 2.4 log b to [-87, 87] as ONE v_med3_f32 (two compares and two
+  // selects as written; equal for every operand that is not NaN, and log b is not NaN for b > 0), its `b > 0 else 0` as a
+  // select at the end instead of a branch around the body (rt_logf of b <= 0 or NaN is garbage that the select drops).
+  // Same bits for every x: rt_test_srgb_sweep.
+  const float b = __builtin_fmaf(r, c, q);
+  const float t = __builtin_amdgcn_fmed3f(2.4f * rt_logf(b), -87.0f, 87.0f);
+  const float p = rt_expf(t);
+  return (b > 0.0f) ? p : 0.0f;
+#endif
 }
 __device__ __forceinline__ rt_v3 srgb_to_linear_tex(rt_v3 v) {
   return rt_v3_make(srgb_to_linear_tex1(v.x), srgb_to_linear_tex1(v.y), srgb_to_linear_tex1(v.z));
