@@ -106,22 +106,24 @@ static int huff_decode(Bits *b, const Huff *h) {
 
 static int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
 
-/* jidctint.c (IJG release 6b): dequantise + inverse DCT of one block into out[8 rows][stride] */
+/* jidctint.c (IJG release 6b): dequantise + inverse DCT of one block into out[8 rows][stride].  64-bit temporaries: the
+ * library's 32-bit ones give the same values on every valid stream and overflow (undefined in C) on damaged ones. */
+typedef int64_t idct_t;
 #define CONST_BITS 13
 #define PASS1_BITS 2
-#define DESCALE(x, n) (((x) + ((int32_t)1 << ((n) - 1))) >> (n))
+#define DESCALE(x, n) (((x) + ((idct_t)1 << ((n) - 1))) >> (n))
 static void idct_islow(const int16_t *coef, const uint16_t *q, uint8_t *out, int stride) {
-  int32_t ws[64];
+  idct_t ws[64];
   for (int c = 0; c < 8; c++) {
     const int16_t *in = coef + c;
     const uint16_t *qq = q + c;
-    int32_t z2 = in[16] * qq[16], z3 = in[48] * qq[48];
-    int32_t z1 = (z2 + z3) * 4433;
-    int32_t tmp2 = z1 + z3 * -15137, tmp3 = z1 + z2 * 6270;
+    idct_t z2 = in[16] * qq[16], z3 = in[48] * qq[48];
+    idct_t z1 = (z2 + z3) * 4433;
+    idct_t tmp2 = z1 + z3 * -15137, tmp3 = z1 + z2 * 6270;
     z2 = in[0] * qq[0];
     z3 = in[32] * qq[32];
-    int32_t tmp0 = (z2 + z3) * (1 << CONST_BITS), tmp1 = (z2 - z3) * (1 << CONST_BITS);
-    int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    idct_t tmp0 = (z2 + z3) * (1 << CONST_BITS), tmp1 = (z2 - z3) * (1 << CONST_BITS);
+    idct_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = in[56] * qq[56];
     tmp1 = in[40] * qq[40];
     tmp2 = in[24] * qq[24];
@@ -129,13 +131,13 @@ static void idct_islow(const int16_t *coef, const uint16_t *q, uint8_t *out, int
     z1 = tmp0 + tmp3;
     z2 = tmp1 + tmp2;
     z3 = tmp0 + tmp2;
-    int32_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
+    idct_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
     tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
     z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
     z3 += z5;
     z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    int32_t *w = ws + c;
+    idct_t *w = ws + c;
     w[0] = DESCALE(tmp10 + tmp3, CONST_BITS - PASS1_BITS);
     w[56] = DESCALE(tmp10 - tmp3, CONST_BITS - PASS1_BITS);
     w[8] = DESCALE(tmp11 + tmp2, CONST_BITS - PASS1_BITS);
@@ -146,26 +148,26 @@ static void idct_islow(const int16_t *coef, const uint16_t *q, uint8_t *out, int
     w[32] = DESCALE(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
   }
   for (int r = 0; r < 8; r++) {
-    const int32_t *w = ws + r * 8;
-    int32_t z2 = w[2], z3 = w[6];
-    int32_t z1 = (z2 + z3) * 4433;
-    int32_t tmp2 = z1 + z3 * -15137, tmp3 = z1 + z2 * 6270;
-    int32_t tmp0 = (w[0] + w[4]) * (1 << CONST_BITS), tmp1 = (w[0] - w[4]) * (1 << CONST_BITS);
-    int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    const idct_t *w = ws + r * 8;
+    idct_t z2 = w[2], z3 = w[6];
+    idct_t z1 = (z2 + z3) * 4433;
+    idct_t tmp2 = z1 + z3 * -15137, tmp3 = z1 + z2 * 6270;
+    idct_t tmp0 = (w[0] + w[4]) * (1 << CONST_BITS), tmp1 = (w[0] - w[4]) * (1 << CONST_BITS);
+    idct_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
     z1 = tmp0 + tmp3;
     z2 = tmp1 + tmp2;
     z3 = tmp0 + tmp2;
-    int32_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
+    idct_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
     tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
     z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
     z3 += z5;
     z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    const int32_t v[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+    const idct_t v[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
     uint8_t *o = out + (size_t)r * stride;
     for (int k = 0; k < 8; k++) {
-      int32_t s = DESCALE(v[k], CONST_BITS + PASS1_BITS + 3) + 128;
+      idct_t s = DESCALE(v[k], CONST_BITS + PASS1_BITS + 3) + 128;
       o[k] = (uint8_t)(s < 0 ? 0 : s > 255 ? 255 : s);
     }
   }
@@ -279,6 +281,9 @@ bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, 
         if (comp[k].h > hmax) hmax = comp[k].h;
         if (comp[k].v > vmax) vmax = comp[k].v;
       }
+      for (int k = 0; k < ncomp; k++)
+        if (hmax % comp[k].h || vmax % comp[k].v) return jfail(err, err_len, "fractional sampling ratios are not supported");
+      if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return jfail(err, err_len, "image larger than 2^28 pixels");
     } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       return jfail(err, err_len, "progressive / lossless / arithmetic JPEG is not supported (use the RT8I side files)");
     } else if (m == 0xDD) {
@@ -291,6 +296,7 @@ bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, 
         if (found < 0) return jfail(err, err_len, "scan names an unknown component");
         comp[found].td = s[2 + 2 * k] >> 4;
         comp[found].ta = s[2 + 2 * k] & 15;
+        if (comp[found].td > 3 || comp[found].ta > 3) return jfail(err, err_len, "bad Huffman table id in the scan header");
       }
       scan = data + i + 2 + len;
       break;
@@ -377,9 +383,9 @@ bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, 
       uint8_t *u = (uint8_t *)malloc((size_t)ow * oh);
       if (!u) { up_ok = false; break; }
       /* jdsample.c jinit_upsampler: the triangle filters only for planes more than two samples wide */
-      const bool exact = hmax % c->h == 0 && vmax % c->v == 0, fancy = c->down_w > 2;
-      if (exact && fancy && hs == 2 && vs == 2) upsample_h2v2(c->plane, c->blocks_w * 8, c->down_w, c->down_h, u, ow);
-      else if (exact && fancy && hs == 2 && vs == 1) upsample_h2v1(c->plane, c->blocks_w * 8, c->down_w, c->down_h, u, ow);
+      const bool fancy = c->down_w > 2;
+      if (fancy && hs == 2 && vs == 2) upsample_h2v2(c->plane, c->blocks_w * 8, c->down_w, c->down_h, u, ow);
+      else if (fancy && hs == 2 && vs == 1) upsample_h2v1(c->plane, c->blocks_w * 8, c->down_w, c->down_h, u, ow);
       else upsample_replicate(c->plane, c->blocks_w * 8, hs, vs, ow, oh, u, ow);
       full[k] = u;
       fstride[k] = ow;

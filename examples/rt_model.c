@@ -757,7 +757,8 @@ static bool load_gltf(char const *path, RT_Model *out, Err *e) {
       if (j_int(j_get(prim, "mode"), 4) != 4) continue;
       Accessor pos, nrm, uv, ind;
       bool has_n = j_get(att, "NORMAL") != NULL, has_uv = j_get(att, "TEXCOORD_0") != NULL, has_i = j_get(prim, "indices") != NULL;
-      ok = j_get(att, "POSITION") && accessor_open(&g, j_int(j_get(att, "POSITION"), -1), &pos, e);
+      ok = j_get(att, "POSITION") ? accessor_open(&g, j_int(j_get(att, "POSITION"), -1), &pos, e)
+                                  : fail(e, "'%s': a primitive without a POSITION attribute", path);
       if (ok && has_n) ok = accessor_open(&g, j_int(j_get(att, "NORMAL"), -1), &nrm, e);
       if (ok && has_uv) ok = accessor_open(&g, j_int(j_get(att, "TEXCOORD_0"), -1), &uv, e);
       if (ok && has_i) ok = accessor_open(&g, j_int(j_get(prim, "indices"), -1), &ind, e);

@@ -224,6 +224,7 @@ bool rt_png_decode(const unsigned char *data, size_t n, Image *out, char *err, s
                 : (depth == 8 || depth == 16);
   if (ctype == 0 && depth == 16) { pfail(err, err_len, "16-bit grayscale PNG is not supported (use the RT8I side files)"); goto done; }
   if (!channels || !depth_ok || w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) { pfail(err, err_len, "unsupported header"); goto done; }
+  if ((size_t)w * (size_t)h > ((size_t)1 << 28)) { pfail(err, err_len, "image larger than 2^28 pixels"); goto done; }
   {
     const size_t bits = (size_t)channels * (size_t)depth, row = ((size_t)w * bits + 7) / 8, bpp = bits >= 8 ? bits / 8 : 1;
     raw = (uint8_t *)malloc((row + 1) * (size_t)h);

@@ -317,6 +317,66 @@ def test_c_loader_decodes_png_images_of_a_gltf(tmp_path):
     assert c["materials"][0].texture_emission == p["materials"][0].texture_emission == 1
 
 
+def test_c_readers_survive_damaged_files_under_sanitizers(tmp_path):
+    """examples/fuzz_images.c: the JPEG and PNG decoders and the OBJ / MTL / glTF / JSON readers of the C host, built with
+    -fsanitize=address,undefined, fed thousands of mutated files (bit flips, random bytes, truncations, spliced blocks): every one
+    either loads or is refused WITH a message; no out-of-bounds access, overflow or leak (the sanitizers abort the run)."""
+    import io
+    import json
+    import shutil
+    from PIL import Image as PI
+    subprocess.check_call(["make", "-C", EX, "fuzz_images"], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(1)
+    a = np.asarray(PI.fromarray(rng.integers(0, 256, (9, 9, 3), dtype=np.uint8)).resize((67, 45), PI.BICUBIC))
+    PI.fromarray(a).save(tmp_path / "f1.jpg", quality=85)
+    PI.fromarray(a).save(tmp_path / "f2.jpg", quality=60, subsampling=0, restart_marker_blocks=3)
+    PI.fromarray(a).convert("L").save(tmp_path / "f3.jpg")
+    PI.fromarray(a).save(tmp_path / "f4.png")
+    PI.fromarray(a).quantize(16).save(tmp_path / "f5.png")
+    PI.fromarray(a[..., 0].copy()).save(tmp_path / "f6.png", compress_level=0)
+    images = [str(tmp_path / f) for f in ("f1.jpg", "f2.jpg", "f3.jpg", "f4.png", "f5.png", "f6.png")]
+    r = subprocess.run([os.path.join(EX, "fuzz_images"), "1500"] + images, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ok, bad = (int(w) for w in r.stdout.split() if w.isdigit())
+    assert ok > 1000 and bad > 1000, r.stdout
+    # models: an OBJ with its MTL and maps, and a .gltf whose JSON names an external buffer, a PNG by uri and one in the buffer
+    for f in ("quad.obj", "quad.mtl"):
+        shutil.copy(os.path.join(ASSETS, f), tmp_path / f)
+    with open(tmp_path / "quad.mtl", "a") as f:
+        f.write("map_Kd f4.png\nmap_Ke f1.jpg\nPr 0.5\nnorm f5.png\n")
+    bio = io.BytesIO()
+    PI.fromarray(a).quantize(40).save(bio, "PNG")
+    emb = bio.getvalue()
+    blob = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32).tobytes() + np.array([[0, 0], [1, 0], [0, 1]], np.float32).tobytes() +
+            np.array([0, 1, 2, 0], np.uint16).tobytes() + emb)
+    (tmp_path / "t.bin").write_bytes(blob)
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 1]}],
+           "nodes": [{"mesh": 0, "translation": [1, 2, 3], "rotation": [0, 0.7071, 0, 0.7071], "scale": [1, 2, 1], "children": [2]},
+                     {"camera": 0, "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 5, 1]}, {"mesh": 0}],
+           "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8, "znear": 0.1}}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2, "material": 0}]}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "baseColorFactor": [1, 0.5, 0.25, 1], "metallicFactor": 0.5},
+                          "emissiveTexture": {"index": 1}, "emissiveFactor": [1, 1, 1], "name": 'm\u00e9tal "q" \\ back',
+                          "extensions": {"KHR_materials_sheen": {"sheenColorFactor": [0.1, 0.2, 0.3]}}}],
+           "textures": [{"source": 0}, {"source": 1}], "images": [{"uri": "f4.png"}, {"bufferView": 3, "mimeType": "image/png"}],
+           "buffers": [{"uri": "t.bin", "byteLength": len(blob)}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24},
+                           {"buffer": 0, "byteOffset": 60, "byteLength": 6}, {"buffer": 0, "byteOffset": 68, "byteLength": len(emb)}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                         {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"},
+                         {"bufferView": 2, "componentType": 5123, "count": 3, "type": "SCALAR"}]}
+    (tmp_path / "t.gltf").write_text(json.dumps(doc))
+    work = tmp_path / "mutants"
+    work.mkdir()
+    for f in ("quad.mtl", "f1.jpg", "f4.png", "f5.png", "t.bin"):           # what the mutants refer to by name
+        shutil.copy(tmp_path / f, work / f)
+    r = subprocess.run([os.path.join(EX, "fuzz_images"), "-m", str(work), "4000", str(tmp_path / "quad.obj"), str(tmp_path / "t.gltf"),
+                        os.path.join(ASSETS, "sheen.glb")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ok, bad = (int(w) for w in r.stdout.split() if w.isdigit())
+    assert ok > 1000 and bad > 1000, r.stdout
+
+
 def test_c_loader_decodes_the_embedded_jpegs_of_the_helmet(tmp_path):
     """No preparation step: helmet.glb by itself (four 2048 x 2048 baseline 4:2:0 JPEGs) -> the texels the Python loader gets."""
     from raytracing_c_amd.loaders import load_model_data
