@@ -37,10 +37,10 @@ def _node_any(c):
 
 
 BLOCKS = [
-    ("SKY_X", "sky loop: a batch of up to 64 camera paths of a tile whose pyramid misses the root (primary ray, fast flag, environment, accumulate)", "SKY_X", "SKY_L", 648, 0.85, 1.15),
+    ("SKY_X", "sky loop: a batch of up to 64 camera paths of a tile whose pyramid misses the root (primary ray, fast flag, environment, accumulate)", "SKY_X", "SKY_L", 624, 0.85, 1.15),
     ("S_ITER", "S block: entry, park decision, counters, exit into the traversal loop", "S_ITER", None, None, 20, 400),
-    ("ENV_X", "S: environment lookup of the misses (atan2, asin, bilinear fetch, 3 x pow)", "ENV_X", "ENV_L", 383, 0.9, 1.1),
-    ("SHADE_T", "S: shade_hit, Disney material with 4 textures (helmet)", _disney_tex, "SHADE_L", 1776, 0.75, 1.05),
+    ("ENV_X", "S: environment lookup of the misses (atan2, asin, bilinear fetch, 3 x pow)", "ENV_X", "ENV_L", 369, 0.9, 1.1),
+    ("SHADE_T", "S: shade_hit, Disney material with 4 textures (helmet)", _disney_tex, "SHADE_L", 1747, 0.75, 1.05),
     ("SHADE_P", "S: shade_hit, Disney material without textures", _disney_plain, "SHADE_L", 1200, 0.6, 1.2),
     ("SHADE_D", "S: shade_hit, debug material (normal -> colour, path ends)", _debug, "SHADE_L", 200, 0.3, 3.0),
     ("PSTORE_X", "S: park hits (18 dwords of path state per hit to memory)", "PSTORE_X", "PSTORE_L", 51, 0.5, 2.0),
@@ -59,7 +59,7 @@ BLOCKS = [
     ("NFEW2_X", "NODE culled, 2 surviving children", "NFEW2_X", "NFEW2_L", 54, 0.6, 1.6),
     ("NFEW3_X", "NODE culled, 3 surviving children", "NFEW3_X", "NFEW3_L", 120, 0.6, 1.4),
     ("NFEW4_X", "NODE culled, 4 surviving children", "NFEW4_X", "NFEW4_L", 138, 0.6, 1.4),
-    ("LEAF_X", "LEAF: 8 Moeller-Trumbore tests (18 x dwordx4, 8 short reciprocals)", "LEAF_X", "LEAF_L", 420, 0.95, 1.08),
+    ("LEAF_X", "LEAF: 8 Moeller-Trumbore tests (18 x dwordx4, 8 short reciprocals; per triangle, the third dot product and the update -- 11 of 49 -- behind a branch the wave skips when no lane passed u and v)", "LEAF_X", "LEAF_L", 391, 0.70, 1.03),
     ("POP_X", "pop iteration: next child of the current node", "POP_X", "POP_L", 27, 0.4, 2.5),
     ("POP_UP_X", "pop iteration: some lane goes up to the nearest live level (perm word from LDS)", "POP_UP_X", "POP_UP_L", 19, 0.5, 2.0),
     ("POP_RETEST_X", "pop iteration: some lane re-tests its child against a closer hit (3 near planes)", "POP_RETEST_X", "POP_RETEST_L", 25, 0.5, 2.5),
