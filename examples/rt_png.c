@@ -7,7 +7,7 @@
  *   gray + alpha, RGB, RGBA   -> alpha dropped; 16-bit samples: the high byte
  *   palette 1 / 2 / 4 / 8     -> PLTE entry (black beyond the end of the table); tRNS ignored
  *   16-bit gray               -> refused (PIL clips it instead of scaling: not something to imitate)
- *   Adam7 interlace           -> refused (no encoder here writes it, nothing could pin it)
+ *   Adam7 interlace           -> the seven passes scattered into place (pinned by hand-written streams that PIL reads)
  *
  * zlib: stored, fixed and dynamic blocks (RFC 1950 / 1951), no preset dictionary; the Adler-32 and the chunk CRCs are not
  * checked (a damaged stream fails in the Huffman decoder or on its length instead).  Filters 0-4 of the PNG specification.
@@ -188,7 +188,7 @@ bool rt_png_decode(const unsigned char *data, size_t n, Image *out, char *err, s
   memset(out, 0, sizeof *out);
   if (n < 8 || memcmp(data, SIG, 8) != 0) return pfail(err, err_len, "not a PNG stream");
   uint32_t w = 0, h = 0;
-  int      depth = 0, ctype = -1, n_pal = 0;
+  int      depth = 0, ctype = -1, n_pal = 0, interlace = 0;
   uint8_t  pal[256][3];
   memset(pal, 0, sizeof pal);
   uint8_t *z = (uint8_t *)malloc(n), *raw = NULL, *rgb = NULL;
@@ -206,7 +206,8 @@ bool rt_png_decode(const unsigned char *data, size_t n, Image *out, char *err, s
       depth = body[8];
       ctype = body[9];
       if (body[10] != 0 || body[11] != 0) { pfail(err, err_len, "unknown compression / filter method"); goto done; }
-      if (body[12] != 0) { pfail(err, err_len, "interlaced PNG is not supported (use the RT8I side files)"); goto done; }
+      if (body[12] > 1) { pfail(err, err_len, "unknown interlace method"); goto done; }
+      interlace = body[12];
     } else if (!memcmp(type, "PLTE", 4)) {
       n_pal = (int)(len / 3 > 256 ? 256 : len / 3);
       memcpy(pal, body, (size_t)n_pal * 3);
@@ -226,35 +227,51 @@ bool rt_png_decode(const unsigned char *data, size_t n, Image *out, char *err, s
   if (!channels || !depth_ok || w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) { pfail(err, err_len, "unsupported header"); goto done; }
   if ((size_t)w * (size_t)h > ((size_t)1 << 28)) { pfail(err, err_len, "image larger than 2^28 pixels"); goto done; }
   {
-    const size_t bits = (size_t)channels * (size_t)depth, row = ((size_t)w * bits + 7) / 8, bpp = bits >= 8 ? bits / 8 : 1;
-    raw = (uint8_t *)malloc((row + 1) * (size_t)h);
+    /* one pass (the whole image) or the seven of Adam7: pass p holds the pixels (x0 + i dx, y0 + j dy), as an image of its own */
+    static const uint8_t X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1}, DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+    const size_t bits = (size_t)channels * (size_t)depth, bpp = bits >= 8 ? bits / 8 : 1;
+    const int n_pass = interlace ? 7 : 1;
+    size_t total = 0;
+    for (int p = 0; p < n_pass; p++) {
+      const size_t pw = interlace ? ((size_t)w + DX[p] - 1 - X0[p]) / DX[p] : w, ph = interlace ? ((size_t)h + DY[p] - 1 - Y0[p]) / DY[p] : h;
+      if (pw && ph) total += ((pw * bits + 7) / 8 + 1) * ph;
+    }
+    raw = (uint8_t *)malloc(total ? total : 1);
     rgb = (uint8_t *)malloc((size_t)w * h * 3);
     if (!raw || !rgb) { pfail(err, err_len, "out of memory"); goto done; }
-    if (!inflate_zlib(z, zn, raw, (row + 1) * (size_t)h)) { pfail(err, err_len, "bad zlib stream (or not the size the header announces)"); goto done; }
-    for (uint32_t y = 0; y < h; y++) {
-      uint8_t *cur = raw + (size_t)y * (row + 1) + 1;
-      const uint8_t *up = y ? cur - (row + 1) : NULL;
-      const int f = cur[-1];
-      if (f > 4) { pfail(err, err_len, "unknown filter type"); goto done; }
-      for (size_t x = 0; x < row; x++) {
-        const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
-        const int add = f == 0 ? 0 : f == 1 ? a : f == 2 ? b : f == 3 ? ((a + b) >> 1) : paeth(a, b, c);
-        cur[x] = (uint8_t)(cur[x] + add);
-      }
-      uint8_t *o = rgb + (size_t)y * w * 3;
-      const int step = depth == 16 ? 2 : 1;                              /* 16-bit samples: the high byte comes first */
-      for (uint32_t x = 0; x < w; x++, o += 3) {
-        if (ctype == 2 || ctype == 6) {
-          const uint8_t *p = cur + (size_t)x * channels * step;
-          o[0] = p[0]; o[1] = p[step]; o[2] = p[2 * step];
-        } else if (ctype == 4) {
-          o[0] = o[1] = o[2] = cur[(size_t)x * 2 * step];
-        } else {
-          const int per = 8 / depth, v = (cur[x / per] >> ((per - 1 - (int)(x % per)) * depth)) & ((1 << depth) - 1);
-          if (ctype == 3) { o[0] = pal[v][0]; o[1] = pal[v][1]; o[2] = pal[v][2]; }
-          else o[0] = o[1] = o[2] = (uint8_t)(v * 255 / ((1 << depth) - 1));
+    if (!inflate_zlib(z, zn, raw, total)) { pfail(err, err_len, "bad zlib stream (or not the size the header announces)"); goto done; }
+    uint8_t *at = raw;
+    for (int p = 0; p < n_pass; p++) {
+      const size_t x0 = interlace ? X0[p] : 0, y0 = interlace ? Y0[p] : 0, dx = interlace ? DX[p] : 1, dy = interlace ? DY[p] : 1;
+      const size_t pw = ((size_t)w + dx - 1 - x0) / dx, ph = ((size_t)h + dy - 1 - y0) / dy;
+      if (!pw || !ph) continue;
+      const size_t row = (pw * bits + 7) / 8;
+      for (size_t y = 0; y < ph; y++) {
+        uint8_t *cur = at + y * (row + 1) + 1;
+        const uint8_t *up = y ? cur - (row + 1) : NULL;
+        const int f = cur[-1];
+        if (f > 4) { pfail(err, err_len, "unknown filter type"); goto done; }
+        for (size_t x = 0; x < row; x++) {
+          const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+          const int add = f == 0 ? 0 : f == 1 ? a : f == 2 ? b : f == 3 ? ((a + b) >> 1) : paeth(a, b, c);
+          cur[x] = (uint8_t)(cur[x] + add);
+        }
+        const int step = depth == 16 ? 2 : 1;                              /* 16-bit samples: the high byte comes first */
+        for (size_t x = 0; x < pw; x++) {
+          uint8_t *o = rgb + ((y0 + y * dy) * (size_t)w + (x0 + x * dx)) * 3;
+          if (ctype == 2 || ctype == 6) {
+            const uint8_t *q = cur + x * (size_t)channels * step;
+            o[0] = q[0]; o[1] = q[step]; o[2] = q[2 * step];
+          } else if (ctype == 4) {
+            o[0] = o[1] = o[2] = cur[x * 2 * step];
+          } else {
+            const int per = 8 / depth, v = (cur[x / per] >> ((per - 1 - (int)(x % per)) * depth)) & ((1 << depth) - 1);
+            if (ctype == 3) { o[0] = pal[v][0]; o[1] = pal[v][1]; o[2] = pal[v][2]; }
+            else o[0] = o[1] = o[2] = (uint8_t)(v * 255 / ((1 << depth) - 1));
+          }
         }
       }
+      at += (row + 1) * ph;
     }
   }
   (void)n_pal;

@@ -206,6 +206,14 @@ def _raw_png(w, h, depth, ctype, rows, plte=None, interlace=0):
     if plte is not None:
         out += chunk(b"PLTE", plte)
     raw = b"".join(b"\0" + r for r in rows)
+    if interlace == 1 and depth >= 8:                            # Adam7: the seven sub-images, each with its own filter bytes
+        bpp = len(rows[0]) // w
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            for y in range(y0, h, dy):
+                px = b"".join(rows[y][x * bpp:(x + 1) * bpp] for x in range(x0, w, dx))
+                if px:
+                    raw += b"\0" + px
     cut = len(raw) // 2                                          # two IDAT chunks: the stream may be split anywhere
     z = zlib.compress(raw)
     return out + chunk(b"IDAT", z[:cut]) + chunk(b"IDAT", z[cut:]) + chunk(b"IEND", b"")
@@ -240,8 +248,14 @@ def test_rt_png_gives_what_pil_gives(size):
         got, msg = _image_decode(lib, data, "rt_png_decode")
         assert got is not None, (depth, ctype, msg)
         assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(data)).convert("RGB"))), (depth, ctype)
+    for depth, ctype, ch in [(8, 2, 3), (8, 6, 4), (8, 0, 1), (16, 2, 3), (8, 3, 1)]:                          # Adam7
+        rows = [bytes(rng.integers(0, 256, w * ch * depth // 8, dtype=np.uint8)) for _ in range(h)]
+        data = _raw_png(w, h, depth, ctype, rows, bytes(rng.integers(0, 256, 768, dtype=np.uint8)) if ctype == 3 else None, interlace=1)
+        got, msg = _image_decode(lib, data, "rt_png_decode")
+        assert got is not None, (depth, ctype, msg)
+        assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(data)).convert("RGB"))), ("adam7", depth, ctype)
     rows = [bytes(2 * w) for _ in range(h)]
-    for data, word in ((_raw_png(w, h, 16, 0, rows), "16-bit grayscale"), (_raw_png(w, h, 8, 0, rows, interlace=1), "interlaced"),
+    for data, word in ((_raw_png(w, h, 16, 0, rows), "16-bit grayscale"), (_raw_png(w, h, 8, 0, rows, interlace=2), "interlace"),
                        (b"\xff\xd8\xff\xe0" + bytes(32), "not a PNG"), (_raw_png(w, h + 1, 8, 0, [bytes(w)] * h), "zlib stream")):
         got, msg = _image_decode(lib, data, "rt_png_decode")
         assert got is None and word in msg, (word, msg)
@@ -334,7 +348,10 @@ def test_c_readers_survive_damaged_files_under_sanitizers(tmp_path):
     PI.fromarray(a).save(tmp_path / "f4.png")
     PI.fromarray(a).quantize(16).save(tmp_path / "f5.png")
     PI.fromarray(a[..., 0].copy()).save(tmp_path / "f6.png", compress_level=0)
-    images = [str(tmp_path / f) for f in ("f1.jpg", "f2.jpg", "f3.jpg", "f4.png", "f5.png", "f6.png")]
+    (tmp_path / "f7.png").write_bytes(_raw_png(37, 21, 8, 2, [bytes(rng.integers(0, 256, 37 * 3, dtype=np.uint8)) for _ in range(21)], interlace=1))
+    (tmp_path / "f8.png").write_bytes(_raw_png(19, 9, 2, 3, [bytes(rng.integers(0, 256, 5, dtype=np.uint8)) for _ in range(9)],
+                                               bytes(rng.integers(0, 256, 12, dtype=np.uint8))))
+    images = [str(tmp_path / f) for f in ("f1.jpg", "f2.jpg", "f3.jpg", "f4.png", "f5.png", "f6.png", "f7.png", "f8.png")]
     r = subprocess.run([os.path.join(EX, "fuzz_images"), "1500"] + images, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ok, bad = (int(w) for w in r.stdout.split() if w.isdigit())
