@@ -4,7 +4,10 @@
  * decodes with PIL, i.e. libjpeg(-turbo) with its defaults.  This decoder restates THOSE defaults so that the C host and the
  * Python loader hand the renderer the same texels, byte for byte (tests/test_c_loader.py compares them):
  *
- *   * sequential baseline DCT (SOF0), 8 bits, 1 or 3 components, Huffman, optional restart intervals;
+ *   * baseline / extended sequential (SOF0 / SOF1) and progressive (SOF2) Huffman streams, 8 bits, 1 or 3 components, any scan
+ *     layout (interleaved or one component per scan), optional restart intervals: every scan goes into coefficient buffers of
+ *     the whole frame (ITU T.81 F.2.2, G.1.2, G.2: DC / AC first passes, the successive-approximation refinements with their
+ *     end-of-band runs), the pixels are made once the last scan is in;
  *   * the "islow" inverse DCT of the IJG library (jidctint.c: Loeffler-Ligtenberg-Moshovitz, 13-bit constants, two passes
  *     with PASS1_BITS = 2);
  *   * "fancy" chroma upsampling (jdsample.c: the triangle filter, 3/4 + 1/4 per direction, with the IJG's alternating
@@ -13,7 +16,7 @@
  *     here writes and no test can pin: replicated);
  *   * YCbCr -> RGB by the IJG's 16-bit fixed-point tables (jdcolor.c).
  *
- * Not a general JPEG library: no progressive, arithmetic, 12-bit, CMYK or 16-bit-table support -- such files fail with a
+ * Not a general JPEG library: no arithmetic coding, 12-bit samples, CMYK or 16-bit tables -- such files fail with a
  * message and the host falls back to the RT8I side files of tools/extract_textures.py.
  */
 #include <stdint.h>
@@ -220,156 +223,281 @@ static void upsample_replicate(const uint8_t *plane, int stride, int hs, int vs,
     for (int x = 0; x < ow; x++) out[(size_t)y * ostride + x] = plane[(size_t)(y / vs) * stride + x / hs];
 }
 
-bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, size_t err_len) {
-  uint16_t qt[4][64];
-  int      qt_present[4] = {0, 0, 0, 0};
-  Huff     dc[4], ac[4];
+/* ---- scans: coefficients of every block first (one scan of a baseline stream, up to dozens of a progressive one), pixels after ---- */
+
+typedef struct {
+  int      width, height, ncomp, hmax, vmax, restart, progressive;
   Comp     comp[3];
-  int      ncomp = 0, width = 0, height = 0, hmax = 1, vmax = 1, restart = 0;
-  bool     ok = false;
-  memset(dc, 0, sizeof dc);
-  memset(ac, 0, sizeof ac);
-  memset(comp, 0, sizeof comp);
+  int16_t *coef[3];            /* blocks_w * blocks_h * 64 per component, natural order */
+  uint16_t qt[4][64];
+  int      qt_present[4];
+  Huff     dc[4], ac[4];
+} Dec;
+
+static int get_bit(Bits *b) { return get_bits(b, 1); }
+
+/* one block of a scan (ITU T.81 F.2.2 for sequential streams, G.1.2 / G.2 for progressive ones) */
+static bool scan_block(Dec *d, Bits *b, Comp *c, int16_t *blk, int ss, int se, int ah, int al, int *eobrun) {
+  if (!d->progressive) {
+    int t = huff_decode(b, &d->dc[c->td]);
+    if (t < 0 || t > 11) return false;
+    c->pred += t ? extend(get_bits(b, t), t) : 0;
+    blk[0] = (int16_t)c->pred;
+    for (int k = 1; k < 64;) {
+      int rs = huff_decode(b, &d->ac[c->ta]);
+      if (rs < 0) return false;
+      int r = rs >> 4, sz = rs & 15;
+      if (sz == 0) {
+        if (r != 15) break;
+        k += 16;
+        continue;
+      }
+      k += r;
+      if (k > 63) return false;
+      blk[ZIGZAG[k]] = (int16_t)extend(get_bits(b, sz), sz);
+      k++;
+    }
+    return true;
+  }
+  if (ss == 0) {                                   /* DC scan: first pass or one more bit */
+    if (ah == 0) {
+      int t = huff_decode(b, &d->dc[c->td]);
+      if (t < 0 || t > 11) return false;
+      c->pred += t ? extend(get_bits(b, t), t) : 0;
+      blk[0] = (int16_t)(c->pred * (1 << al));
+    } else if (get_bit(b)) {
+      blk[0] |= (int16_t)(1 << al);
+    }
+    return true;
+  }
+  const int p1 = 1 << al, m1 = -(1 << al);
+  if (ah == 0) {                                   /* AC scan, first pass of the band ss .. se */
+    if (*eobrun > 0) { (*eobrun)--; return true; }
+    for (int k = ss; k <= se; k++) {
+      int rs = huff_decode(b, &d->ac[c->ta]);
+      if (rs < 0) return false;
+      int r = rs >> 4, sz = rs & 15;
+      if (sz == 0) {
+        if (r < 15) {
+          *eobrun = (1 << r) - 1;
+          if (r) *eobrun += get_bits(b, r);
+          break;
+        }
+        k += 15;
+      } else {
+        k += r;
+        if (k > se) return false;
+        blk[ZIGZAG[k]] = (int16_t)(extend(get_bits(b, sz), sz) * (1 << al));
+      }
+    }
+    return true;
+  }
+  int k = ss;                                      /* AC scan, one more bit for the band */
+  if (*eobrun == 0) {
+    for (; k <= se; k++) {
+      int rs = huff_decode(b, &d->ac[c->ta]);
+      if (rs < 0) return false;
+      int r = rs >> 4, sz = rs & 15, val = 0;
+      if (sz) {
+        if (sz != 1) return false;
+        val = get_bit(b) ? p1 : m1;
+      } else if (r != 15) {
+        *eobrun = 1 << r;
+        if (r) *eobrun += get_bits(b, r);
+        break;
+      }
+      do {                                         /* pass r coefficients that are still zero; the non-zero ones on the way get their bit */
+        int16_t *q = &blk[ZIGZAG[k]];
+        if (*q != 0) {
+          if (get_bit(b) && (*q & p1) == 0) *q = (int16_t)(*q + (*q >= 0 ? p1 : m1));
+        } else if (--r < 0) {
+          break;
+        }
+        k++;
+      } while (k <= se);
+      if (val) {
+        if (k > se) return false;
+        blk[ZIGZAG[k]] = (int16_t)val;
+      }
+    }
+  }
+  if (*eobrun > 0) {
+    for (; k <= se; k++) {
+      int16_t *q = &blk[ZIGZAG[k]];
+      if (*q != 0 && get_bit(b) && (*q & p1) == 0) *q = (int16_t)(*q + (*q >= 0 ? p1 : m1));
+    }
+    (*eobrun)--;
+  }
+  return true;
+}
+
+/* the entropy-coded segment after an SOS header; returns the offset of the marker that ends it (0: failure) */
+static size_t decode_scan(Dec *d, const uint8_t *data, size_t n, size_t at, int n_sc, const int *sc, int ss, int se, int ah, int al, char *err, size_t err_len) {
+  Bits b;
+  memset(&b, 0, sizeof b);
+  b.p = data + at;
+  b.end = data + n;
+  for (int k = 0; k < n_sc; k++) d->comp[sc[k]].pred = 0;
+  int eobrun = 0, until_restart = d->restart, next_rst = 0;
+  /* one component: its blocks in raster order, as many as cover the image; several: MCU by MCU */
+  Comp *c0 = &d->comp[sc[0]];
+  const int mcus_x = n_sc == 1 ? (c0->down_w + 7) / 8 : (d->width + 8 * d->hmax - 1) / (8 * d->hmax);
+  const int mcus_y = n_sc == 1 ? (c0->down_h + 7) / 8 : (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
+  for (int my = 0; my < mcus_y; my++)
+    for (int mx = 0; mx < mcus_x; mx++) {
+      if (d->restart && until_restart == 0) {
+        b.bitbuf = 0;
+        b.bitcnt = 0;
+        if (b.marker == 0) {
+          while (b.p + 1 < b.end && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) b.p++;
+          if (b.p + 1 < b.end) b.p += 2;
+        } else if (b.marker != 0xD0 + next_rst) { jfail(err, err_len, "restart marker out of sequence"); return 0; }
+        b.marker = 0;
+        next_rst = (next_rst + 1) & 7;
+        until_restart = d->restart;
+        eobrun = 0;
+        for (int k = 0; k < n_sc; k++) d->comp[sc[k]].pred = 0;
+      }
+      for (int k = 0; k < n_sc; k++) {
+        Comp *c = &d->comp[sc[k]];
+        const int nh = n_sc == 1 ? 1 : c->h, nv = n_sc == 1 ? 1 : c->v;
+        for (int by = 0; by < nv; by++)
+          for (int bx = 0; bx < nh; bx++) {
+            const size_t col = (size_t)mx * nh + bx, row = (size_t)my * nv + by;
+            if (col >= (size_t)c->blocks_w || row >= (size_t)c->blocks_h) { jfail(err, err_len, "block outside the frame"); return 0; }
+            if (!scan_block(d, &b, c, d->coef[sc[k]] + (row * c->blocks_w + col) * 64, ss, se, ah, al, &eobrun)) { jfail(err, err_len, "bad entropy-coded data"); return 0; }
+          }
+      }
+      if (d->restart) until_restart--;
+    }
+  /* the marker that ends the scan: already met by the bit reader, or ahead of it */
+  if (b.marker) return (size_t)(b.p - data) - 2;
+  const uint8_t *q = b.p;
+  while (q + 1 < b.end && !(q[0] == 0xFF && q[1] != 0 && !(q[1] >= 0xD0 && q[1] <= 0xD7))) q++;
+  return (size_t)(q - data);
+}
+
+bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, size_t err_len) {
+  Dec  *d = (Dec *)calloc(1, sizeof *d);
+  bool  ok = false, frame = false, scanned = false;
   memset(out, 0, sizeof *out);
-  if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return jfail(err, err_len, "not a JPEG stream");
-  size_t i = 2;
-  const uint8_t *scan = NULL;
-  while (i + 4 <= n) {
-    if (data[i] != 0xFF) return jfail(err, err_len, "marker expected");
+  if (!d) return jfail(err, err_len, "out of memory");
+  d->hmax = d->vmax = 1;
+  if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) { jfail(err, err_len, "not a JPEG stream"); goto done; }
+  for (size_t i = 2; i + 4 <= n;) {
+    if (data[i] != 0xFF) { jfail(err, err_len, "marker expected"); goto done; }
     int m = data[i + 1];
     if (m == 0xFF) { i++; continue; }
+    if (m == 0xD9) break;                                                     /* EOI */
     if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
     size_t len = ((size_t)data[i + 2] << 8) | data[i + 3];
-    if (len < 2 || i + 2 + len > n) return jfail(err, err_len, "truncated segment");
+    if (len < 2 || i + 2 + len > n) { jfail(err, err_len, "truncated segment"); goto done; }
     const uint8_t *s = data + i + 4;
     size_t sl = len - 2;
     if (m == 0xDB) {
       while (sl >= 65) {
         int pq = s[0] >> 4, tq = s[0] & 15;
-        if (pq != 0 || tq > 3) return jfail(err, err_len, "16-bit quantisation tables are not supported");
-        for (int k = 0; k < 64; k++) qt[tq][ZIGZAG[k]] = s[1 + k];
-        qt_present[tq] = 1;
+        if (pq != 0 || tq > 3) { jfail(err, err_len, "16-bit quantisation tables are not supported"); goto done; }
+        for (int k = 0; k < 64; k++) d->qt[tq][ZIGZAG[k]] = s[1 + k];
+        d->qt_present[tq] = 1;
         s += 65;
         sl -= 65;
       }
     } else if (m == 0xC4) {
       while (sl >= 17) {
         int tc = s[0] >> 4, th = s[0] & 15;
-        if (tc > 1 || th > 3) return jfail(err, err_len, "bad Huffman table id");
-        Huff *h = tc ? &ac[th] : &dc[th];
+        if (tc > 1 || th > 3) { jfail(err, err_len, "bad Huffman table id"); goto done; }
+        Huff *h = tc ? &d->ac[th] : &d->dc[th];
         int total = 0;
         h->bits[0] = 0;
         for (int k = 1; k <= 16; k++) { h->bits[k] = s[k]; total += s[k]; }
-        if (total > 256 || sl < (size_t)(17 + total)) return jfail(err, err_len, "bad Huffman table");
+        if (total > 256 || sl < (size_t)(17 + total)) { jfail(err, err_len, "bad Huffman table"); goto done; }
         memcpy(h->vals, s + 17, (size_t)total);
         huff_build(h);
         s += 17 + total;
         sl -= (size_t)(17 + total);
       }
-    } else if (m == 0xC0 || m == 0xC1) {
-      if (sl < 6 || s[0] != 8) return jfail(err, err_len, "only 8-bit baseline JPEG is supported");
-      height = (s[1] << 8) | s[2];
-      width = (s[3] << 8) | s[4];
-      ncomp = s[5];
-      if ((ncomp != 1 && ncomp != 3) || width <= 0 || height <= 0 || sl < (size_t)(6 + 3 * ncomp)) return jfail(err, err_len, "unsupported frame header");
-      for (int k = 0; k < ncomp; k++) {
-        comp[k].id = s[6 + 3 * k];
-        comp[k].h = s[7 + 3 * k] >> 4;
-        comp[k].v = s[7 + 3 * k] & 15;
-        comp[k].tq = s[8 + 3 * k];
-        if (comp[k].h < 1 || comp[k].h > 4 || comp[k].v < 1 || comp[k].v > 4 || comp[k].tq > 3) return jfail(err, err_len, "bad sampling factors");
-        if (comp[k].h > hmax) hmax = comp[k].h;
-        if (comp[k].v > vmax) vmax = comp[k].v;
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      if (frame) { jfail(err, err_len, "two frame headers"); goto done; }
+      if (sl < 6 || s[0] != 8) { jfail(err, err_len, "only 8-bit JPEG is supported"); goto done; }
+      d->progressive = m == 0xC2;
+      d->height = (s[1] << 8) | s[2];
+      d->width = (s[3] << 8) | s[4];
+      d->ncomp = s[5];
+      if ((d->ncomp != 1 && d->ncomp != 3) || d->width <= 0 || d->height <= 0 || sl < (size_t)(6 + 3 * d->ncomp)) { jfail(err, err_len, "unsupported frame header"); goto done; }
+      if ((size_t)d->width * (size_t)d->height > ((size_t)1 << 28)) { jfail(err, err_len, "image larger than 2^28 pixels"); goto done; }
+      for (int k = 0; k < d->ncomp; k++) {
+        Comp *c = &d->comp[k];
+        c->id = s[6 + 3 * k];
+        c->h = s[7 + 3 * k] >> 4;
+        c->v = s[7 + 3 * k] & 15;
+        c->tq = s[8 + 3 * k];
+        if (c->h < 1 || c->h > 4 || c->v < 1 || c->v > 4 || c->tq > 3) { jfail(err, err_len, "bad sampling factors"); goto done; }
+        if (c->h > d->hmax) d->hmax = c->h;
+        if (c->v > d->vmax) d->vmax = c->v;
       }
-      for (int k = 0; k < ncomp; k++)
-        if (hmax % comp[k].h || vmax % comp[k].v) return jfail(err, err_len, "fractional sampling ratios are not supported");
-      if ((size_t)width * (size_t)height > ((size_t)1 << 28)) return jfail(err, err_len, "image larger than 2^28 pixels");
-    } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-      return jfail(err, err_len, "progressive / lossless / arithmetic JPEG is not supported (use the RT8I side files)");
+      if (d->ncomp == 1) d->comp[0].h = d->comp[0].v = d->hmax = d->vmax = 1;   /* one component: its sampling factors mean nothing */
+      const int mcus_x = (d->width + 8 * d->hmax - 1) / (8 * d->hmax), mcus_y = (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
+      for (int k = 0; k < d->ncomp; k++) {
+        Comp *c = &d->comp[k];
+        if (d->hmax % c->h || d->vmax % c->v) { jfail(err, err_len, "fractional sampling ratios are not supported"); goto done; }
+        c->blocks_w = mcus_x * c->h;
+        c->blocks_h = mcus_y * c->v;
+        c->down_w = (d->width * c->h + d->hmax - 1) / d->hmax;
+        c->down_h = (d->height * c->v + d->vmax - 1) / d->vmax;
+        d->coef[k] = (int16_t *)calloc((size_t)c->blocks_w * c->blocks_h * 64, sizeof(int16_t));
+        if (!d->coef[k]) { jfail(err, err_len, "out of memory"); goto done; }
+      }
+      frame = true;
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      jfail(err, err_len, "lossless / hierarchical / arithmetic-coded JPEG is not supported (use the RT8I side files)");
+      goto done;
     } else if (m == 0xDD) {
-      if (sl >= 2) restart = (s[0] << 8) | s[1];
+      if (sl >= 2) d->restart = (s[0] << 8) | s[1];
     } else if (m == 0xDA) {
-      if (ncomp == 0 || sl < (size_t)(1 + 2 * s[0] + 3) || s[0] != ncomp) return jfail(err, err_len, "unsupported scan header (one interleaved scan expected)");
-      for (int k = 0; k < ncomp; k++) {
+      if (!frame || sl < 1 || s[0] < 1 || s[0] > d->ncomp || sl < (size_t)(1 + 2 * s[0] + 3)) { jfail(err, err_len, "bad scan header"); goto done; }
+      int n_sc = s[0], sc[3];
+      for (int k = 0; k < n_sc; k++) {
         int cid = s[1 + 2 * k], found = -1;
-        for (int c = 0; c < ncomp; c++) if (comp[c].id == cid) found = c;
-        if (found < 0) return jfail(err, err_len, "scan names an unknown component");
-        comp[found].td = s[2 + 2 * k] >> 4;
-        comp[found].ta = s[2 + 2 * k] & 15;
-        if (comp[found].td > 3 || comp[found].ta > 3) return jfail(err, err_len, "bad Huffman table id in the scan header");
+        for (int c = 0; c < d->ncomp; c++) if (d->comp[c].id == cid) found = c;
+        if (found < 0) { jfail(err, err_len, "scan names an unknown component"); goto done; }
+        for (int j = 0; j < k; j++) if (sc[j] == found) { jfail(err, err_len, "scan names a component twice"); goto done; }
+        sc[k] = found;
+        d->comp[found].td = s[2 + 2 * k] >> 4;
+        d->comp[found].ta = s[2 + 2 * k] & 15;
+        if (d->comp[found].td > 3 || d->comp[found].ta > 3) { jfail(err, err_len, "bad Huffman table id in the scan header"); goto done; }
       }
-      scan = data + i + 2 + len;
-      break;
+      const int ss = s[1 + 2 * n_sc], se = s[2 + 2 * n_sc], ah = s[3 + 2 * n_sc] >> 4, al = s[3 + 2 * n_sc] & 15;
+      if (d->progressive ? (ss > se || se > 63 || al > 13 || ah > 13 || (ss == 0 && se != 0) || (ss > 0 && n_sc != 1)) : (ss != 0 || se != 63 || ah || al)) {
+        jfail(err, err_len, "bad spectral selection / successive approximation");
+        goto done;
+      }
+      for (int k = 0; k < n_sc; k++) {
+        Comp *c = &d->comp[sc[k]];
+        const bool need_dc = !d->progressive || (ss == 0 && ah == 0), need_ac = !d->progressive || ss > 0;
+        if ((need_dc && !d->dc[c->td].present) || (need_ac && !d->ac[c->ta].present)) { jfail(err, err_len, "a Huffman table the scan needs is missing"); goto done; }
+      }
+      size_t next = decode_scan(d, data, n, i + 2 + len, n_sc, sc, ss, se, ah, al, err, err_len);
+      if (!next) goto done;
+      scanned = true;
+      i = next;
+      continue;
     }
     i += 2 + len;
   }
-  if (!scan) return jfail(err, err_len, "no scan");
-  const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
-  const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
-  for (int k = 0; k < ncomp; k++) {
-    Comp *c = &comp[k];
-    if (!qt_present[c->tq] || !dc[c->td].present || !ac[c->ta].present) { jfail(err, err_len, "a table the scan needs is missing"); goto done; }
-    c->blocks_w = mcus_x * c->h;
-    c->blocks_h = mcus_y * c->v;
-    c->down_w = (width * c->h + hmax - 1) / hmax;
-    c->down_h = (height * c->v + vmax - 1) / vmax;
+  if (!frame || !scanned) { jfail(err, err_len, "no scan"); goto done; }
+  for (int k = 0; k < d->ncomp; k++) {
+    Comp *c = &d->comp[k];
+    if (!d->qt_present[c->tq]) { jfail(err, err_len, "a quantisation table the frame needs is missing"); goto done; }
     c->plane = (uint8_t *)malloc((size_t)c->blocks_w * 8 * (size_t)c->blocks_h * 8);
     if (!c->plane) { jfail(err, err_len, "out of memory"); goto done; }
+    for (int by = 0; by < c->blocks_h; by++)
+      for (int bx = 0; bx < c->blocks_w; bx++)
+        idct_islow(d->coef[k] + ((size_t)by * c->blocks_w + bx) * 64, d->qt[c->tq], c->plane + (size_t)by * 8 * c->blocks_w * 8 + (size_t)bx * 8, c->blocks_w * 8);
   }
   {
-    Bits b;
-    memset(&b, 0, sizeof b);
-    b.p = scan;
-    b.end = data + n;
-    int16_t coef[64];
-    int     until_restart = restart, next_rst = 0;
-    for (int my = 0; my < mcus_y; my++)
-      for (int mx = 0; mx < mcus_x; mx++) {
-        if (restart && until_restart == 0) {
-          /* byte-align, expect RSTn */
-          b.bitbuf = 0;
-          b.bitcnt = 0;
-          if (b.marker == 0) {
-            while (b.p + 1 < b.end && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) b.p++;
-            if (b.p + 1 < b.end) b.p += 2;
-          } else if (b.marker != 0xD0 + next_rst) { jfail(err, err_len, "restart marker out of sequence"); goto done; }
-          b.marker = 0;
-          next_rst = (next_rst + 1) & 7;
-          until_restart = restart;
-          for (int k = 0; k < ncomp; k++) comp[k].pred = 0;
-        }
-        for (int k = 0; k < ncomp; k++) {
-          Comp *c = &comp[k];
-          for (int by = 0; by < c->v; by++)
-            for (int bx = 0; bx < c->h; bx++) {
-              memset(coef, 0, sizeof coef);
-              int t = huff_decode(&b, &dc[c->td]);
-              if (t < 0 || t > 11) { jfail(err, err_len, "bad DC code"); goto done; }
-              int diff = t ? extend(get_bits(&b, t), t) : 0;
-              c->pred += diff;
-              coef[0] = (int16_t)c->pred;
-              for (int kk = 1; kk < 64;) {
-                int rs = huff_decode(&b, &ac[c->ta]);
-                if (rs < 0) { jfail(err, err_len, "bad AC code"); goto done; }
-                int r = rs >> 4, sz = rs & 15;
-                if (sz == 0) {
-                  if (r != 15) break;
-                  kk += 16;
-                  continue;
-                }
-                kk += r;
-                if (kk > 63) { jfail(err, err_len, "AC coefficient out of range"); goto done; }
-                coef[ZIGZAG[kk]] = (int16_t)extend(get_bits(&b, sz), sz);
-                kk++;
-              }
-              const int px = (mx * c->h + bx) * 8, py = (my * c->v + by) * 8;
-              idct_islow(coef, qt[c->tq], c->plane + (size_t)py * c->blocks_w * 8 + px, c->blocks_w * 8);
-            }
-        }
-        if (restart) until_restart--;
-      }
-  }
-  {
+    const int width = d->width, height = d->height, ncomp = d->ncomp, hmax = d->hmax, vmax = d->vmax;
+    Comp *comp = d->comp;
     uint8_t *rgb = (uint8_t *)malloc((size_t)width * height * 3);
     uint8_t *full[3] = {NULL, NULL, NULL};
     int      fstride[3] = {0, 0, 0};
@@ -429,6 +557,7 @@ bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, 
     ok = true;
   }
 done:
-  for (int k = 0; k < 3; k++) free(comp[k].plane);
+  for (int k = 0; k < 3; k++) { free(d->comp[k].plane); free(d->coef[k]); }
+  free(d);
   return ok;
 }

@@ -4,7 +4,7 @@
  *
  * Texels of image k of a model: the side file `<model path>.image<k>.rgb8` when it exists (16-byte header "RT8I", i32
  * width, height, components, then the rows; tools/extract_textures.py writes them from any codec PIL reads), else the
- * stream the glTF file embeds or names, decoded by rt_jpeg.c when it is a baseline JPEG (helmet.glb's four images:
+ * stream the glTF file embeds or names, decoded by rt_jpeg.c when it is a baseline or progressive JPEG (helmet.glb's four images:
  * libjpeg's default arithmetic restated, so both routes give the same bytes) or by rt_png.c when it is a PNG.  A
  * material that references an image neither route can produce fails the load with a message.  The map_Kd / map_Ke /
  * norm / map_Pm files of a .mtl are decoded the same way (a file that does not exist is no map, as in loaders.py).
@@ -46,7 +46,7 @@ Camera rt_model_camera(f32 const translation[3], f32 const rotation[4], f32 yfov
 /* one RT8I side file (what image k of a model is read from) -> Image; used for the environment map too */
 bool rt_model_load_rgb8(char const *path, Image *out, char *err, size_t err_len);
 
-/* rt_jpeg.c: a baseline JPEG stream (what helmet.glb embeds) -> RGB8 Image with libjpeg's default arithmetic (islow IDCT,
+/* rt_jpeg.c: a baseline or progressive JPEG stream (what helmet.glb embeds) -> RGB8 Image with libjpeg's default arithmetic (islow IDCT,
  * fancy upsampling), i.e. the texels the Python loader gets from PIL; pixels.data is malloc'ed.  false + message otherwise. */
 bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, size_t err_len);
 /* rt_png.c: a non-interlaced PNG stream -> RGB8 Image the way PIL's .convert("RGB") maps it (alpha dropped, palette applied,

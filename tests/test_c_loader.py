@@ -126,12 +126,12 @@ def test_c_loader_fails_loudly(tmp_path):
     assert not lib.rt_model_load(str(tmp_path / "nothing.obj").encode(), C.byref(m), err, 512) and b"cannot read" in err.value
     assert not lib.rt_model_load(b"model.fbx", C.byref(m), err, 512) and b"Unrecognized file type" in err.value     # driver.c:724-727
     blob = bytearray(open(os.path.join(ASSETS, "helmet.glb"), "rb").read())   # a codec rt_jpeg.c does not read, no side files
-    at = blob.index(b"\xff\xc0\x00\x11\x08")                 # SOF0 of the first embedded image -> SOF2 (progressive)
-    blob[at + 1] = 0xC2
-    bad = tmp_path / "helmet_progressive.glb"
+    at = blob.index(b"\xff\xc0\x00\x11\x08")                 # SOF0 of the first embedded image -> SOF9 (arithmetic coding)
+    blob[at + 1] = 0xC9
+    bad = tmp_path / "helmet_arithmetic.glb"
     bad.write_bytes(bytes(blob))
     assert not lib.rt_model_load(str(bad).encode(), C.byref(m), err, 512)
-    assert b"progressive" in err.value and b"extract_textures" in err.value
+    assert b"arithmetic" in err.value and b"extract_textures" in err.value
 
 
 def _jpeg_decode(lib, data):
@@ -170,10 +170,15 @@ def test_rt_jpeg_is_libjpeg_bit_for_bit(size):
         got, msg = _jpeg_decode(lib, data)
         assert got is not None, (kw, msg)
         assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(data)).convert("RGB"))), kw
-    bio = io.BytesIO()
-    im.save(bio, "JPEG", progressive=True)
-    got, msg = _jpeg_decode(lib, bio.getvalue())
-    assert got is None and "progressive" in msg
+    for src, kw in [(im, dict(progressive=True)), (noisy, dict(progressive=True, quality=92, subsampling=0)),
+                    (im, dict(progressive=True, quality=40, subsampling=1)), (im.convert("L"), dict(progressive=True)),
+                    (noisy, dict(progressive=True, quality=75, restart_marker_blocks=2)), (im, dict(progressive=True, optimize=True, quality=97))]:
+        bio = io.BytesIO()
+        src.save(bio, "JPEG", **kw)
+        assert b"\xff\xc2" in bio.getvalue()                                  # SOF2: DC / AC bands, successive approximation, EOB runs
+        got, msg = _jpeg_decode(lib, bio.getvalue())
+        assert got is not None, (kw, msg)
+        assert np.array_equal(got, np.asarray(PI.open(io.BytesIO(bio.getvalue())).convert("RGB"))), kw
     got, msg = _jpeg_decode(lib, b"\x89PNG\r\n\x1a\n" + bytes(64))
     assert got is None and "not a JPEG" in msg
     got, msg = _jpeg_decode(lib, data[: len(data) // 3])              # truncated entropy-coded data: zeros are fed, no crash
@@ -345,13 +350,14 @@ def test_c_readers_survive_damaged_files_under_sanitizers(tmp_path):
     PI.fromarray(a).save(tmp_path / "f1.jpg", quality=85)
     PI.fromarray(a).save(tmp_path / "f2.jpg", quality=60, subsampling=0, restart_marker_blocks=3)
     PI.fromarray(a).convert("L").save(tmp_path / "f3.jpg")
+    PI.fromarray(a).save(tmp_path / "f9.jpg", quality=80, progressive=True)
     PI.fromarray(a).save(tmp_path / "f4.png")
     PI.fromarray(a).quantize(16).save(tmp_path / "f5.png")
     PI.fromarray(a[..., 0].copy()).save(tmp_path / "f6.png", compress_level=0)
     (tmp_path / "f7.png").write_bytes(_raw_png(37, 21, 8, 2, [bytes(rng.integers(0, 256, 37 * 3, dtype=np.uint8)) for _ in range(21)], interlace=1))
     (tmp_path / "f8.png").write_bytes(_raw_png(19, 9, 2, 3, [bytes(rng.integers(0, 256, 5, dtype=np.uint8)) for _ in range(9)],
                                                bytes(rng.integers(0, 256, 12, dtype=np.uint8))))
-    images = [str(tmp_path / f) for f in ("f1.jpg", "f2.jpg", "f3.jpg", "f4.png", "f5.png", "f6.png", "f7.png", "f8.png")]
+    images = [str(tmp_path / f) for f in ("f1.jpg", "f2.jpg", "f3.jpg", "f4.png", "f5.png", "f6.png", "f7.png", "f8.png", "f9.jpg")]
     r = subprocess.run([os.path.join(EX, "fuzz_images"), "1500"] + images, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ok, bad = (int(w) for w in r.stdout.split() if w.isdigit())
