@@ -629,6 +629,26 @@ def main():
     tot = rt.render.Counters(*[int(v) for v in stats.tolist()])
     last_ms = float(kms.item())
 
+    # N > 1: what rank 0 holds after the gather must BE the frame -- the same bytes as one rank rendering every chunk (per-path
+    # seeds depend on pixel and sample only).  Checked after the timed region, reported in the line, and fatal when it fails.
+    dist_check = None
+    if rank == 0 and multi:
+        import hashlib
+        gathered = host_images[(frame_no[0] - 1) & 1].numpy()
+        whole = abi.RT_Render_Params(w, h, s, b, 0x1234ABCD, 0, 1, args.slab, 0)
+        acc1, img1 = torch.zeros_like(accums[0]), torch.zeros_like(images[0])
+        st = torch.cuda.current_stream().cuda_stream
+        if rt.lib.rt_render_accumulate(dscenes[0], C.byref(whole), acc1.data_ptr(), st) != 0 or \
+                rt.lib.rt_resolve(C.byref(whole), acc1.data_ptr(), None, img1.data_ptr(), None, st) != 0:
+            raise RuntimeError(rt.last_error())
+        torch.cuda.synchronize()
+        sha_n = hashlib.sha256(gathered.tobytes()).hexdigest()
+        sha_1 = hashlib.sha256(img1.cpu().numpy().tobytes()).hexdigest()
+        dist_check = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "devices": sorted({local_rank}) if "RT_BENCH_DEVICE" in os.environ else "one per rank (LOCAL_RANK)",
+                      "image_sha256": sha_n, "one_rank_image_sha256": sha_1, "equal": sha_n == sha_1}
+        del acc1, img1
+
     if rank == 0:
         sec_per_step = elapsed / max(args.steps, 1)
         rays = tot.rays
@@ -649,7 +669,8 @@ def main():
         out = {
             "metric": "Mray/s", "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "the reference's own model file (geometry + textures) under a procedural environment map; no dataset involved",
             "config": {"workload": workload,
                        "scene": f"assets/{cfg['asset']}" + (" = self-contained models/helmet.gltf" if "helmet" in cfg["asset"] else "")
                                 + "; procedural 2048x1024 equirect background (background.png is a missing blob); seed 0x1234ABCD",
@@ -679,6 +700,8 @@ def main():
             out["config"]["boundary"] = boundary_cost(rt, abi, hs)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, args.cpu_seconds)
+        if dist_check is not None:
+            out["distributed"] = dist_check
         if args.save:
             from PIL import Image
             Image.fromarray(host_images[(frame_no[0] - 1) & 1].numpy()).save(args.save)
@@ -690,6 +713,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if dist_check is not None and not dist_check["equal"]:
+        print(f"bench.py: the gathered frame of {world} ranks differs from the one-rank frame: {dist_check}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

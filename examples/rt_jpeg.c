@@ -48,6 +48,7 @@ typedef struct {
   uint32_t bitbuf;
   int      bitcnt;
   int      marker;           /* a marker met inside the entropy-coded data */
+  int      starved;          /* bytes of zero padding fed after the input ended WITHOUT a marker: a truncated stream */
 } Bits;
 
 static const uint8_t ZIGZAG[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
@@ -83,6 +84,8 @@ static void fill_bits(Bits *b) {
         if (c2 == 0) b->p++;                       /* stuffed zero */
         else { b->marker = c2; b->p++; c = 0; }    /* a marker: feed zeros from here on */
       }
+    } else if (b->marker == 0) {
+      b->starved++;                                /* the data ended in the middle of a scan */
     }
     b->bitbuf |= (uint32_t)c << (24 - b->bitcnt);
     b->bitcnt += 8;
@@ -368,6 +371,8 @@ static size_t decode_scan(Dec *d, const uint8_t *data, size_t n, size_t at, int 
             if (!scan_block(d, &b, c, d->coef[sc[k]] + (row * c->blocks_w + col) * 64, ss, se, ah, al, &eobrun)) { jfail(err, err_len, "bad entropy-coded data"); return 0; }
           }
       }
+      /* (the bit reader looks 4 bytes ahead: only padding that was actually CONSUMED means the scan ran past the end) */
+      if (b.starved > 4) { jfail(err, err_len, "truncated entropy-coded data"); return 0; }
       if (d->restart) until_restart--;
     }
   /* the marker that ends the scan: already met by the bit reader, or ahead of it */
@@ -426,6 +431,8 @@ bool rt_jpeg_decode(const unsigned char *data, size_t n, Image *out, char *err, 
       d->ncomp = s[5];
       if ((d->ncomp != 1 && d->ncomp != 3) || d->width <= 0 || d->height <= 0 || sl < (size_t)(6 + 3 * d->ncomp)) { jfail(err, err_len, "unsupported frame header"); goto done; }
       if ((size_t)d->width * (size_t)d->height > ((size_t)1 << 28)) { jfail(err, err_len, "image larger than 2^28 pixels"); goto done; }
+      /* a few hundred bytes must not command gigabytes of coefficient buffers: an MCU block costs at least ~1 bit per scan */
+      if ((size_t)d->width * (size_t)d->height / 64 > n * 64 + 4096) { jfail(err, err_len, "frame header claims more pixels than the stream can hold"); goto done; }
       for (int k = 0; k < d->ncomp; k++) {
         Comp *c = &d->comp[k];
         c->id = s[6 + 3 * k];

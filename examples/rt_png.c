@@ -236,6 +236,9 @@ bool rt_png_decode(const unsigned char *data, size_t n, Image *out, char *err, s
       const size_t pw = interlace ? ((size_t)w + DX[p] - 1 - X0[p]) / DX[p] : w, ph = interlace ? ((size_t)h + DY[p] - 1 - Y0[p]) / DY[p] : h;
       if (pw && ph) total += ((pw * bits + 7) / 8 + 1) * ph;
     }
+    /* deflate expands at most ~1032 : 1 -- a header whose pixels the IDAT bytes cannot possibly fill is refused before it
+     * commands the buffers */
+    if (total / 1032 > zn + 64) { pfail(err, err_len, "header claims more pixels than the IDAT data can hold"); goto done; }
     raw = (uint8_t *)malloc(total ? total : 1);
     rgb = (uint8_t *)malloc((size_t)w * h * 3);
     if (!raw || !rgb) { pfail(err, err_len, "out of memory"); goto done; }

@@ -36,6 +36,9 @@
  *     traversal statistics) and the denoiser (pinned by a numpy restatement)
  *     keep their arithmetic under both contracts.
  *
+ * Numeric contract v3 (round 5) = v2 with a cheaper, more accurate power for the
+ * sRGB decode (rt_pow24 below); -DRT_MATH_V2 keeps round 4's arithmetic.
+ *
  * Polynomial coefficients are the classic single-precision minimax sets
  * (Cephes, S. Moshier) for log/exp/sin/cos/atan/asin.
  */
@@ -80,8 +83,20 @@ RT_FN float rt_fractf(float x) { return x - rt_floorf(x); }   /* raytracer.c:582
 #define RT_MATH_CONTRACT 1
 RT_FN float rt_madd(float a, float b, float c) { return a * b + c; }
 #else
+#ifdef RT_MATH_V2
 #define RT_MATH_CONTRACT 2
+#else
+#define RT_MATH_CONTRACT 3
+#endif
 RT_FN float rt_madd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+/* Contract v3 (round 5) = v2 + the sRGB decode's power through rt_pow24() below instead of exp(2.4 log x): a change of this
+ * build's OWN libm stand-in (the reference calls codin's pow_f32, common.h:84), closer to the true power than the old one and
+ * half its instructions.  -DRT_MATH_V2 (on both compilers) keeps round 4's decode; contract v1 implies it. */
+#if RT_MATH_CONTRACT >= 3
+#define RT_MATH_POW24 1
+#else
+#define RT_MATH_POW24 0
 #endif
 /* a0*b0 + a1*b1 + a2*b2, folded left to right */
 RT_FN float rt_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
@@ -175,11 +190,23 @@ RT_FN float rt_lerpf_plain(float x, float y, float t) { return x * (1.0f - t) + 
  * Contract v2, NaN-free rays:  t = fma(plane, inv, bias) with bias = -(o * inv), ONE instruction per plane instead
  * of two.  A ray is NaN-free ("fast") when, per axis, the reciprocal direction and the bias are finite: then the
  * exact product plane * inv is a finite real, bias is finite, and the fused result is finite or an overflowed
- * infinity -- never NaN -- and it is monotonic in `plane`, which the device code's pick-by-address relies on. */
+ * infinity -- never NaN -- and it is monotonic in `plane`, which the device code's pick-by-address relies on.
+ *
+ * DOMAIN of the fused form (round 5, deviation D9).  fma(plane, inv, bias) rounds twice: bias = RN(o * inv), off by at most
+ * 2^-24 |o * inv|, and the result, off by at most 2^-24 |t|.  The first error does not shrink with the distance: it moves
+ * the plane by up to 2^-24 |o| in SPACE, where the reference's (plane - o) * inv places a nearby plane (Sterbenz: the
+ * difference of two floats within a factor of two is exact) to within 2^-23 of its DISTANCE.  scene.c pads every leaf box by
+ * EPSILON = 1e-4 and the slab test clamps to EPSILON, so a grazing ray decides differently once 2^-24 |o| approaches that
+ * padding (measured: primary-hit counts of the two forms differ from |o| ~ 1e5, tests/test_oracle_contracts.py).  A ray
+ * therefore takes the fused form only while every origin component is below RT_SLAB_FUSED_MAX_ORIGIN = 256: placement
+ * error < 2^-16 = 0.153 EPSILON.  Rays from farther out -- a camera or a scene far from the origin -- keep the reference's
+ * form on the CPU and on the GPU alike (same shared predicate), at the cost of the slower exact node blocks. */
+#define RT_SLAB_FUSED_MAX_ORIGIN 256.0f
 RT_FN float rt_slab_bias(float o, float inv) { return -(o * inv); }
-RT_FN int rt_slab_fast(float inv_x, float inv_y, float inv_z, float bias_x, float bias_y, float bias_z) {
+RT_FN int rt_slab_fast(float ox, float oy, float oz, float inv_x, float inv_y, float inv_z, float bias_x, float bias_y, float bias_z) {
   return (rt_absf(inv_x) < RT_INF) && (rt_absf(inv_y) < RT_INF) && (rt_absf(inv_z) < RT_INF) &&
-         (rt_absf(bias_x) < RT_INF) && (rt_absf(bias_y) < RT_INF) && (rt_absf(bias_z) < RT_INF);
+         (rt_absf(bias_x) < RT_INF) && (rt_absf(bias_y) < RT_INF) && (rt_absf(bias_z) < RT_INF) &&
+         (rt_absf(ox) < RT_SLAB_FUSED_MAX_ORIGIN) && (rt_absf(oy) < RT_SLAB_FUSED_MAX_ORIGIN) && (rt_absf(oz) < RT_SLAB_FUSED_MAX_ORIGIN);
 }
 RT_FN float rt_slab_t_exact(float plane, float o, float inv) { return (plane - o) * inv; }
 #ifdef RT_MATH_NO_FMA
@@ -302,10 +329,45 @@ RT_FN float rt_asinf(float x) {
   return x < 0.0f ? -p : p;
 }
 
+/* b ^ 2.4 for the sRGB decode (common.h:84-91: pow_f32((x + 0.055) / 1.055, 2.4)), contract v3.
+ * b = m 2^-n with m in [1, 2):  b^2.4 = P(m - 1.5) * 2^(-2.4 n),  P the degree-6 minimax polynomial of m^2.4 on [1, 2)
+ * (relative fit error 2.2e-8) and 2^(-2.4 n) one of six constants.  The CORE is defined for
+ * 2^-5 <= b < 2 -- every b a texture sample can produce: x in [0, 1] gives b in [0.0521, 1] -- where its result is within
+ * 3.7 ulp (2.2e-7 relative) of the true power for EVERY float (all 6 x 2^23 of them compared with pow() in double: 3.63 ulp at
+ * worst; tests/test_oracle_kat.py compares every fifth); exp(2.4 log b) of contract v2 was within 1.1e-6.  Outside (and for NaN) rt_pow24() is rt_powf():
+ * 0 for b <= 0 or NaN as before.  7 fused multiply-adds / multiplies, 2 integer operations, 5 compare + select pairs. */
+RT_FN float rt_pow24_core(float b) {
+  const float t = rt_u2f((rt_f2u(b) & 0x007fffffu) | 0x3f800000u) - 1.5f;
+  float p = -1.257556141e-03f;
+  p = rt_fmaf(p, t,  3.908345941e-03f);
+  p = rt_fmaf(p, t, -1.751393452e-02f);
+  p = rt_fmaf(p, t,  1.756089926e-01f);
+  p = rt_fmaf(p, t,  1.975808740e+00f);
+  p = rt_fmaf(p, t,  4.233884811e+00f);
+  p = rt_fmaf(p, t,  2.646177769e+00f);
+  /* 2^(-2.4 n), n = 0 .. 5, rounded to nearest; picked by comparisons with the binade boundaries (a chain of five selects:
+   * written over the bits of the exponent, hipcc turned the select tree into divergent branches) */
+  float s = 1.0f;
+  s = (b < 1.0f)     ? 1.894645691e-01f : s;
+  s = (b < 0.5f)     ? 3.589682281e-02f : s;
+  s = (b < 0.25f)    ? 6.801176351e-03f : s;
+  s = (b < 0.125f)   ? 1.288581989e-03f : s;
+  s = (b < 0.0625f)  ? 2.441406250e-04f : s;
+  return p * s;
+}
+RT_FN float rt_pow24(float b) {
+  if (!(b >= 0x1p-5f && b < 2.0f)) return rt_powf(b, 2.4f);
+  return rt_pow24_core(b);
+}
+
 /* ---- colour (common.h:82-92) -------------------------------------------------- */
 
 /* NOTE: no linear toe segment, exactly like the reference. */
+#if RT_MATH_POW24
+RT_FN float rt_srgb_to_linear1(float x) { return rt_pow24((x + 0.055f) / 1.055f); }
+#else
 RT_FN float rt_srgb_to_linear1(float x) { return rt_powf((x + 0.055f) / 1.055f, 2.4f); }
+#endif
 
 RT_FN rt_v3 rt_srgb_to_linear(rt_v3 c) {
   return rt_v3_make(rt_srgb_to_linear1(c.x), rt_srgb_to_linear1(c.y), rt_srgb_to_linear1(c.z));

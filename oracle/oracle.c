@@ -187,7 +187,7 @@ static void ray_aabbs_hit_8_avx2(Ray const *ray, f32 t_min, f32 t_max, BVH_Node 
   f32 inv_x = 1.0f / ray->direction.x, inv_y = 1.0f / ray->direction.y, inv_z = 1.0f / ray->direction.z;
   f32 ox = ray->position.x, oy = ray->position.y, oz = ray->position.z;
   f32 bias_x = rt_slab_bias(ox, inv_x), bias_y = rt_slab_bias(oy, inv_y), bias_z = rt_slab_bias(oz, inv_z);
-  bool fast = rt_slab_fast(inv_x, inv_y, inv_z, bias_x, bias_y, bias_z);
+  bool fast = rt_slab_fast(ox, oy, oz, inv_x, inv_y, inv_z, bias_x, bias_y, bias_z);
   __m256 ix = _mm256_set1_ps(inv_x), iy = _mm256_set1_ps(inv_y), iz = _mm256_set1_ps(inv_z);
   __m256 mnx = _mm256_loadu_ps(node->min_x), mny = _mm256_loadu_ps(node->min_y), mnz = _mm256_loadu_ps(node->min_z);
   __m256 mxx = _mm256_loadu_ps(node->max_x), mxy = _mm256_loadu_ps(node->max_y), mxz = _mm256_loadu_ps(node->max_z);
@@ -264,7 +264,7 @@ static void ray_aabbs_hit_8_scalar(Ray const *ray, f32 t_min, f32 t_max, BVH_Nod
   /* numeric contract v2 (rt_math.h): NaN-free rays take every plane distance from ONE fused multiply-add,
    * fma(plane, inv, -(o * inv)); the others keep the reference's (plane - o) * inv (deviation D9) */
   f32 bias_x = rt_slab_bias(ox, inv_x), bias_y = rt_slab_bias(oy, inv_y), bias_z = rt_slab_bias(oz, inv_z);
-  bool fast = rt_slab_fast(inv_x, inv_y, inv_z, bias_x, bias_y, bias_z);
+  bool fast = rt_slab_fast(ox, oy, oz, inv_x, inv_y, inv_z, bias_x, bias_y, bias_z);
 
   for (int k = 0; k < 8; k++) {
     f32 t0x, t0y, t0z, t1x, t1y, t1z;

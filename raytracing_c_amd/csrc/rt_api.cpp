@@ -356,6 +356,12 @@ extern "C" void rt_diag_set_tokens(void *disney, void *debug, void *background) 
 // ---------------------------------------------------------------------------------
 // scene residency
 
+struct FpBlock {            // one block of a host scene's full fingerprint (scene_fingerprint_blocks)
+  const void *begin;
+  size_t      bytes;
+  uint64_t    h;
+};
+
 struct RT_Device_Scene {
   Device      *dev = nullptr;
   float       *nodes = nullptr;
@@ -373,6 +379,10 @@ struct RT_Device_Scene {
   uint64_t     stamp = 0;
   std::vector<const void *> mat_ptrs;     // distinct shader.data pointers, upload order
   std::vector<int32_t>      mat_first_tri;   // a triangle that uses mat_ptrs[k]
+  // the FULL fingerprint of the host scene this copy was made from (scene_fingerprint_blocks), refreshed by rt_scene_touch:
+  // every device slot checks a frame against ITS OWN copy's value
+  std::vector<FpBlock>      fp_blocks;
+  uint64_t                  full_fp = 0;
   // what rt_scene_touch() needs to patch the copy in place
   std::unordered_map<uint64_t, int> mat_map;            // (shader.data, kind) -> material id
   std::vector<const Image *>        tex_sources;        // Image of texture k (pool order; the background is one of them)
@@ -553,21 +563,37 @@ static uint64_t hash_image(uint64_t h, Image const *img) {
 }
 
 
-static uint64_t scene_fingerprint(Scene const *scene) {
+// The full fingerprint as a list of BLOCKS -- the dimensions, the node array, each of the nine coordinate arrays, the AoS
+// records, every distinct material record, the texels of every image it references, the background image -- each with the
+// host range it covers: rt_scene_touch() uses the ranges to tell the block the host says it wrote from blocks that changed
+// without a word (those drop the copy instead of being absorbed into the new reference).
+static void fp_image(std::vector<FpBlock> &out, Image const *img) {
+  if (!img) { out.push_back({nullptr, 0, mix64(0x1234u, 0)}); return; }
+  size_t n = 0;
+  if (img->pixels.data && img->pixel_type == PT_u8 && img->width > 0 && img->height > 0 && img->stride >= img->width && img->components > 0) {
+    n = (size_t)img->stride * img->height * img->components;
+    if (img->pixels.len < (isize)n) n = 0;
+  }
+  out.push_back({n ? img->pixels.data : nullptr, n, hash_image(0x51ED27u, img)});
+}
+
+static void scene_fingerprint_blocks(Scene const *scene, std::vector<FpBlock> &out) {
+  out.clear();
   const Triangles &T = scene->triangles;
-  uint64_t h = 0x452821E638D01377ull;
+  const uint64_t h0 = 0x452821E638D01377ull;
   int64_t dims[5] = {(int64_t)scene->bvh.depth, (int64_t)scene->bvh.last_row_offset, (int64_t)scene->bvh.nodes.len,
                      (int64_t)T.len, (int64_t)(uintptr_t)scene->background.proc};
-  h = hash_bytes(h, dims, sizeof dims);
-  if (scene->bvh.nodes.data && scene->bvh.nodes.len > 0)
-    h = hash_bytes(h, scene->bvh.nodes.data, (size_t)scene->bvh.nodes.len * sizeof(BVH_Node));
+  out.push_back({nullptr, 0, hash_bytes(h0, dims, sizeof dims)});
+  if (scene->bvh.nodes.data && scene->bvh.nodes.len > 0) {
+    const size_t n = (size_t)scene->bvh.nodes.len * sizeof(BVH_Node);
+    out.push_back({scene->bvh.nodes.data, n, hash_bytes(h0, scene->bvh.nodes.data, n)});
+  }
   if (T.len > 0 && T.x[0] && T.aos) {
     for (int k = 0; k < 3; k++) {                // the nine coordinate arrays (one block in scene_init, but not required to be)
-      h = hash_bytes(h, T.x[k], (size_t)T.len * 4);
-      h = hash_bytes(h, T.y[k], (size_t)T.len * 4);
-      h = hash_bytes(h, T.z[k], (size_t)T.len * 4);
+      const float *arrs[3] = {T.x[k], T.y[k], T.z[k]};
+      for (const float *a : arrs) out.push_back({a, (size_t)T.len * 4, hash_bytes(h0, a, (size_t)T.len * 4)});
     }
-    h = hash_bytes(h, T.aos, (size_t)T.len * sizeof(Triangle_AOS));
+    out.push_back({T.aos, (size_t)T.len * sizeof(Triangle_AOS), hash_bytes(h0, T.aos, (size_t)T.len * sizeof(Triangle_AOS))});
     const void *last = nullptr;                  // distinct material records, in first-use order
     std::vector<const void *> seen;
     for (int i = 0; i < T.len; i++) {
@@ -580,17 +606,28 @@ static uint64_t scene_fingerprint(Scene const *scene) {
       seen.push_back(sh.data);
       if (sh.proc == g_tok_disney || sh.proc == g_tok_debug) {
         const PBR_Shader_Data *m = (const PBR_Shader_Data *)sh.data;
-        h = hash_bytes(h, m, sizeof *m);
-        h = hash_image(h, m->texture_albedo);
-        h = hash_image(h, m->texture_normal);
-        h = hash_image(h, m->texture_metal_roughness);
-        h = hash_image(h, m->texture_emission);
+        out.push_back({m, sizeof *m, hash_bytes(h0, m, sizeof *m)});
+        fp_image(out, m->texture_albedo);
+        fp_image(out, m->texture_normal);
+        fp_image(out, m->texture_metal_roughness);
+        fp_image(out, m->texture_emission);
       }
       if (seen.size() > 4096) break;             // pathological material counts: the pointers are in the AoS hash anyway
     }
   }
-  if (scene->background.proc == g_tok_background) h = hash_image(h, (Image const *)scene->background.data);
+  if (scene->background.proc == g_tok_background) fp_image(out, (Image const *)scene->background.data);
+}
+
+static uint64_t fp_fold(const std::vector<FpBlock> &blocks) {
+  uint64_t h = 0x452821E638D01377ull;
+  for (const FpBlock &b : blocks) h = mix64(mix64(h, b.h), (uint64_t)b.bytes);
   return h;
+}
+
+static uint64_t scene_fingerprint(Scene const *scene) {
+  std::vector<FpBlock> blocks;
+  scene_fingerprint_blocks(scene, blocks);
+  return fp_fold(blocks);
 }
 
 
@@ -871,7 +908,9 @@ extern "C" void rt_scene_release(RT_Device_Scene *dscene) {
   free_device_scene(dscene);
 }
 
+static void forget_static(Scene const *scene);
 extern "C" void rt_scene_invalidate(Scene const *scene) {
+  forget_static(scene);             // (a Scene rebuilt or freed and allocated again at this address starts checked, like a new one)
   for (int i = 0; i < RT_MAX_DEVICES; i++) {
     Device &D = g_devs[i];
     std::lock_guard<std::mutex> lock(D.mutex);
@@ -904,6 +943,10 @@ extern "C" void rt_scene_set_static(Scene const *scene, i32 is_static) {
   std::lock_guard<std::mutex> lock(g_static_mutex);
   if (is_static) g_static_scenes[scene] = true;
   else g_static_scenes.erase(scene);
+}
+static void forget_static(Scene const *scene) {
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  g_static_scenes.erase(scene);
 }
 static bool scene_is_static(Scene const *scene) {
   std::lock_guard<std::mutex> lock(g_static_mutex);
@@ -1013,12 +1056,21 @@ static int touch_device_scene(RT_Device_Scene *d, Scene const *scene, const void
   return 0;
 }
 
-static std::unordered_map<const Scene *, uint64_t> g_full_fp;     // full fingerprint at upload / after a touch; guarded by g_fp_mutex
-static std::mutex g_fp_mutex;
+// Does [begin, begin + bytes) lie inside block `b`?
+static bool fp_block_holds(const FpBlock &b, const void *begin, size_t bytes) {
+  size_t off;
+  return b.begin && range_in(begin, bytes, b.begin, b.bytes, &off);
+}
+
 // 0 = every resident copy was patched in place, 1 = copies were dropped (the next frame uploads), -1 = error
 extern "C" int rt_scene_touch(Scene const *scene, void const *begin, size_t bytes) {
   if (!scene || !begin || bytes == 0) return rt_fail("rt_scene_touch: NULL scene or empty range");
-  int dropped = 0, patched = 0;
+  // The host scene as it is NOW, block by block.  A copy may be patched only if the blocks that differ from what it was made
+  // from are the one(s) the caller says it wrote: anything else is an edit nobody reported, and taking the new fingerprint
+  // as the reference would hide it from every later check -- such a copy is dropped instead.
+  std::vector<FpBlock> now;
+  scene_fingerprint_blocks(scene, now);
+  int dropped = 0;
   for (int i = 0; i < RT_MAX_DEVICES; i++) {
     Device &D = g_devs[i];
     std::lock_guard<std::mutex> lock(D.mutex);
@@ -1026,10 +1078,17 @@ extern "C" int rt_scene_touch(Scene const *scene, void const *begin, size_t byte
     if (it == D.scene_cache.end()) continue;
     DeviceGuard guard(D);
     RT_Device_Scene *d = it->second;
-    int rc = touch_device_scene(d, scene, begin, (size_t)bytes);
+    bool unreported = now.size() != d->fp_blocks.size();
+    for (size_t k = 0; !unreported && k < now.size(); k++) {
+      const FpBlock &a = now[k], &b = d->fp_blocks[k];
+      if (a.begin != b.begin || a.bytes != b.bytes) unreported = true;
+      else if (a.h != b.h && !fp_block_holds(a, begin, bytes)) unreported = true;
+    }
+    int rc = unreported ? 0 : touch_device_scene(d, scene, begin, (size_t)bytes);
     if (rc == 1) {
       d->stamp = scene_stamp(scene, d->mat_ptrs, d->mat_first_tri);
-      patched += 1;
+      d->fp_blocks = now;
+      d->full_fp = fp_fold(now);
     } else {
       free_device_scene(d);
       D.scene_cache.erase(it);
@@ -1037,33 +1096,37 @@ extern "C" int rt_scene_touch(Scene const *scene, void const *begin, size_t byte
       if (rc < 0) return -1;
     }
   }
-  if (patched) {
-    const uint64_t fp = scene_fingerprint(scene);
-    std::lock_guard<std::mutex> lock(g_fp_mutex);
-    g_full_fp[scene] = fp;
-  }
   return dropped ? 1 : 0;
 }
 
-// Full content check of the cached device copy of `scene` on the primary device: 1 = the host scene still equals what was
-// uploaded (geometry and material bytes in full, texels of large images sampled), 0 = it changed (the copy is dropped,
-// the next frame uploads again), -1 = no cached copy.  The per-frame check is scene_stamp() above.
-static bool fingerprint_matches(Scene const *scene) {
-  const uint64_t now = scene_fingerprint(scene);
-  std::lock_guard<std::mutex> lock(g_fp_mutex);
-  auto fp = g_full_fp.find(scene);
-  return fp != g_full_fp.end() && fp->second == now;
+// Full content check of the cached device copies of `scene`: 1 = the host scene still equals what every copy was made from
+// (geometry and material bytes in full, texels of large images sampled), 0 = it changed (the copies that differ are dropped
+// on EVERY device, the next frame uploads again), -1 = no cached copy on the primary device.  The per-frame check is
+// scene_stamp() above.
+static int drop_stale_copies(Scene const *scene, uint64_t now, int first_slot) {      // returns how many copies were dropped
+  int dropped = 0;
+  for (int i = first_slot; i < RT_MAX_DEVICES; i++) {
+    Device &D = g_devs[i];
+    std::lock_guard<std::mutex> lock(D.mutex);
+    auto it = D.scene_cache.find(scene);
+    if (it == D.scene_cache.end() || it->second->full_fp == now) continue;
+    DeviceGuard guard(D);
+    (void)hipDeviceSynchronize();
+    free_device_scene(it->second);
+    D.scene_cache.erase(it);
+    dropped += 1;
+  }
+  return dropped;
 }
 extern "C" int rt_scene_verify(Scene const *scene) {
-  Device &D = dev0();
-  std::lock_guard<std::mutex> lock(D.mutex);
-  auto it = D.scene_cache.find(scene);
-  if (it == D.scene_cache.end() || !scene) return -1;
-  if (fingerprint_matches(scene)) return 1;
-  DeviceGuard guard(D);
-  free_device_scene(it->second);
-  D.scene_cache.erase(it);
-  return 0;
+  if (!scene) return -1;
+  {
+    Device &D = dev0();
+    std::lock_guard<std::mutex> lock(D.mutex);
+    if (D.scene_cache.find(scene) == D.scene_cache.end()) return -1;
+  }
+  const uint64_t now = scene_fingerprint(scene);
+  return drop_stale_copies(scene, now, 0) == 0 ? 1 : 0;
 }
 
 static void scene_only_kparams(RT_KParams *K, RT_Device_Scene *d) {
@@ -1096,11 +1159,8 @@ static RT_Device_Scene *cached_scene_locked(Device &D, Scene const *scene, float
   RT_Device_Scene *d = upload_scene_locked(D, scene);
   if (d) {
     D.scene_cache[scene] = d;
-    if (D.slot == 0) {
-      const uint64_t fp = scene_fingerprint(scene);
-      std::lock_guard<std::mutex> lock(g_fp_mutex);
-      g_full_fp[scene] = fp;
-    }
+    scene_fingerprint_blocks(scene, d->fp_blocks);      // (every slot keeps its own: a slot can be uploaded long after slot 0)
+    d->full_fp = fp_fold(d->fp_blocks);
   }
   if (upload_ms) *upload_ms = (float)(now_ms() - t1);
   return d;
@@ -1188,6 +1248,10 @@ static void drop_device_partitions(const Partition *q) {        // g_partition_m
 static void remap_device_slots() {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return;
+  // A multi-device frame holds slot 0's mutex from start to end and keeps using the other slots' events, pinned buffers and
+  // streams after their workers have released THEIR mutexes (gather, counter sums): tearing a slot down needs slot 0's mutex
+  // first.  Lock order everywhere: slot 0 -> slot r -> g_partition_mutex.
+  std::lock_guard<std::mutex> frame_lock(dev0().mutex);
   const Config c = config();
   for (int r = 1; r < RT_MAX_DEVICES; r++) {
     Device &D = g_devs[r];
@@ -1624,7 +1688,7 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
       }
     K.short_div = (d->max_edge <= 0x1p38f && cam_max <= 0x1p16f) ? 1 : 0;
     if (knob_int("RT_SHORT_DIV", 1) == 0) K.short_div = 0;
-    // hits parked until a dense shade block can be made of them: 18 x 128 dwords per wave
+    // hits parked until a dense shade block can be made of them: RT_PARK_RECORD_DWORDS = 18 fields x 128 records per wave
     K.park = nullptr;
     if (!wavefront && knob_int("RT_PARK", 1) != 0 && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
       const int grid_waves = (n_waves + 15) / 16 * 16;         // whole workgroups of 16 waves are launched
@@ -1632,7 +1696,7 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
         (void)hipFree(d->park);
         d->park = nullptr;
         d->park_waves = 0;
-        HIP_TRY(hipMalloc(&d->park, (size_t)grid_waves * 18 * 128 * 4));
+        HIP_TRY(hipMalloc(&d->park, (size_t)grid_waves * RT_PARK_RECORD_DWORDS * 4));
         d->park_waves = grid_waves;
       }
       K.park = d->park;
@@ -1839,6 +1903,7 @@ struct MultiFrame {
   int               rcs[RT_MAX_DEVICES];
   bool              staged[RT_MAX_DEVICES];
   float             stamp_ms[RT_MAX_DEVICES], upload_ms[RT_MAX_DEVICES], enqueue_ms[RT_MAX_DEVICES];
+  uint64_t          full_fp[RT_MAX_DEVICES];       // the full fingerprint of the copy each slot rendered from
   char              err[RT_MAX_DEVICES][256];
   std::mutex              m;
   std::condition_variable cv;
@@ -1881,11 +1946,13 @@ static void enqueue_device_frame(MultiFrame &J, int r) {
   J.rcs[r] = -1;
   J.staged[r] = false;
   J.err[r][0] = 0;
+  J.full_fp[r] = 0;
   D.slot = r;
   if (ensure_device(D) != 0) { device_fail(J, r, rt_last_error()); return; }       // assigns D.phys and makes it this thread's device
   if (fault_fails(r)) { device_fail(J, r, "injected failure (rt_diag_multi_fault)"); return; }
   RT_Device_Scene *d = cached_scene_locked(D, J.scene, &J.stamp_ms[r], &J.upload_ms[r]);
   if (!d) { device_fail(J, r, rt_last_error()); return; }
+  J.full_fp[r] = d->full_fp;                                 // what THIS slot's copy was made from
   const double t_enq = now_ms();
   Workspace &W = D.ws;
   if (ensure_frame_buffers(D, J.w, J.h, J.tiles_bytes, r == 0 ? J.tiles_bytes * (size_t)J.world : 0) != 0) { device_fail(J, r, rt_last_error()); return; }
@@ -1986,9 +2053,10 @@ static int render_frame_multi(Scene const *scene, Image const *image, RT_Render_
     enqueue_device_frame(J, 0);
     // the full content check of the host scene while every device renders (see rt_scene_touch)
     bool stale = false;
+    uint64_t fp_now = 0;
     if (verify && attempt == 0) {
       const double t_v = now_ms();
-      stale = !fingerprint_matches(scene);
+      fp_now = scene_fingerprint(scene);
       T.verify_ms = (float)(now_ms() - t_v);
     }
     {
@@ -1998,15 +2066,21 @@ static int render_frame_multi(Scene const *scene, Image const *image, RT_Render_
     int failed = -1;
     for (int r = 0; r < world; r++)
       if (J.rcs[r] != 0 && failed < 0) failed = r;
-    if (J.upload_ms[0] > 0.0f) stale = false;          // (slot 0 uploaded in this very frame: the fingerprint is that upload's)
+    // every slot against the fingerprint of ITS OWN copy: slot r >= 1 may hold a copy made before an in-place edit that
+    // slot 0 has long re-uploaded (one fingerprint per Scene* let such a copy through)
+    if (verify && attempt == 0)
+      for (int r = 0; r < world; r++)
+        if (J.rcs[r] == 0 && J.full_fp[r] != fp_now) stale = true;
     if (failed >= 0 || stale) {
       // nothing may still be writing into slot 0's tile buffer, or reading a scene copy, when we leave or start over
       for (int r = 0; r < world; r++)
         if (J.rcs[r] == 0) (void)hipEventSynchronize(g_devs[r].ws.ev_frame[4]);
       if (failed >= 0) return rt_fail("multi-device frame failed: %s", J.err[failed][0] ? J.err[failed] : "unknown error");
-      auto it = D0.scene_cache.find(scene);
-      if (it != D0.scene_cache.end()) { free_device_scene(it->second); D0.scene_cache.erase(it); }
-      drop_scene_everywhere_but0(scene, world);
+      {                                               // drop the copies that do not match the host scene as it is now
+        auto it = D0.scene_cache.find(scene);
+        if (it != D0.scene_cache.end() && it->second->full_fp != fp_now) { free_device_scene(it->second); D0.scene_cache.erase(it); }
+        drop_stale_copies(scene, fp_now, 1);
+      }
       continue;                                       // the host scene changed under the cached copies: upload and render again
     }
     break;
@@ -2109,7 +2183,7 @@ static int render_frame_locked(Scene const *scene, Image const *image, isize sam
     // unchanged scene waits for max(kernel, check) instead of kernel + check; a changed scene is uploaded and rendered again
     if (!verify || attempt > 0 || upload_ms > 0.0f) break;
     const double t_v = now_ms();
-    const bool same = fingerprint_matches(scene);
+    const bool same = scene_fingerprint(scene) == d->full_fp;
     T.verify_ms = (float)(now_ms() - t_v);
     if (same) break;
     HIP_TRY(hipStreamSynchronize(stream));

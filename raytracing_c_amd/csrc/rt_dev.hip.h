@@ -94,8 +94,12 @@ enum {
   LG_CYC_S, LG_CYC_NODE, LG_CYC_LEAF, LG_CYC_POP, LG_CYC_WAVE, LG_CYC_TILE,
   // the loop of tiles whose pyramid misses the root (round 4): batches of up to 64 camera paths, primary ray -> environment
   LG_SKY_X, LG_SKY_L, LG_CYC_SKY,
+  // small-launch ledger (round 5, tools/exp_small.py): the workgroup's copy of the tree into LDS, the join scans, and the DRAIN of a
+  // tile -- from the moment its last unit is handed out to this wave until the wave's last path of it has ended (RT_LEDGER >= 2)
+  LG_CYC_COPY, LG_CYC_JOIN, LG_CYC_DRAIN, LG_DRAIN_X, LG_DRAIN_L, LG_CYC_FLUSH,
   LG_N
 };
+#define RT_LEDGER_ROW 128      /* dwords per wave in g_ledger (LG_N <= 128 = RT_N_COUNTERS - 8) */
 // The counters live in MEMORY, one row of 64 dwords per wave (g_ledger, rt_kernels.hip), bumped by lane 0 with atomics that
 // return nothing: as scalar registers they did not fit beside the kernel's own (59 of them: 286 spilled VGPRs; even a
 // dozen: 50-80), which would have measured a different kernel.  -DRT_LEDGER=1 counts blocks and lanes, =2 adds the
@@ -119,9 +123,13 @@ __device__ __forceinline__ void lg_add(uint32_t *lg, int slot, uint32_t n) {
 #if defined(RT_LEDGER) && RT_LEDGER >= 2
 #define LGT0() const unsigned long long lg_t0 = __builtin_amdgcn_s_memtime()
 #define LGT1(slot) LG((slot), (uint32_t)((__builtin_amdgcn_s_memtime() - lg_t0) >> 4))
+#define LGD0(n_live) do { if (!lg_drain_t0) { lg_drain_t0 = __builtin_amdgcn_s_memtime(); LG(LG_DRAIN_X, 1); LG(LG_DRAIN_L, (n_live)); } } while (0)
+#define LGD1() do { if (lg_drain_t0) { LG(LG_CYC_DRAIN, (uint32_t)((__builtin_amdgcn_s_memtime() - lg_drain_t0) >> 4)); lg_drain_t0 = 0ull; } } while (0)
 #else
 #define LGT0() ((void)0)
 #define LGT1(slot) ((void)0)
+#define LGD0(n_live) ((void)0)
+#define LGD1() ((void)0)
 #endif
 
 __device__ __forceinline__ float4 ld4(const float *base, int idx4) {
@@ -705,7 +713,15 @@ __device__ __forceinline__ float srgb_to_linear_tex1(float x) {
   float a = x + 0.055f;
   float q = a * c;
   float r = __builtin_fmaf(-1.055f, q, a);
-#ifdef RT_EXP_POW_PLAIN
+#if RT_MATH_POW24
+  // contract v3 (rt_math.h): b^2.4 by rt_pow24_core() -- a degree-6 polynomial in the mantissa times one of six constants -- for
+  // every b in [2^-5, 2), which is every b a texture sample produces; NaN (NaN texture coordinates) and values no u8 texture
+  // yields take rt_powf() in a branch the wave skips.  Same bits as rt_srgb_to_linear1() for every x in [0, 2]: rt_test_srgb_sweep.
+  const float b = __builtin_fmaf(r, c, q);
+  float p = rt_pow24_core(b);
+  if (!(b >= 0x1p-5f && b < 2.0f)) p = rt_powf(b, 2.4f);
+  return p;
+#elif defined(RT_EXP_POW_PLAIN)
   return rt_powf(__builtin_fmaf(r, c, q), 2.4f);
 #else
   // rt_powf(b, 2.4f) (rt_math.h) straight-line: its clamp of 2.4 log b to [-87, 87] as ONE v_med3_f32 (two compares and two
@@ -1018,7 +1034,7 @@ __device__ __forceinline__ void ray_setup(Ray3 &r, rt_v3 o, rt_v3 d) {
     r.inv_y = 1.0f / d.y;
     r.inv_z = 1.0f / d.z;
   }
-  r.fast = rt_slab_fast(r.inv_x, r.inv_y, r.inv_z, rt_slab_bias(o.x, r.inv_x), rt_slab_bias(o.y, r.inv_y), rt_slab_bias(o.z, r.inv_z));
+  r.fast = rt_slab_fast(o.x, o.y, o.z, r.inv_x, r.inv_y, r.inv_z, rt_slab_bias(o.x, r.inv_x), rt_slab_bias(o.y, r.inv_y), rt_slab_bias(o.z, r.inv_z));
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -1090,6 +1106,7 @@ __device__ __forceinline__ bool shade_hit(const PT &P, const HitRec &hit, rt_v3 
 
 #define RT_PARK_FIELDS 18     // hit (t, triangle, u, v), ray origin and direction, tint, emission, rng, pixel of the tile | bounce << 6
 #define RT_PARK_CAP 128       // parked hits per wave (fewer than RT_PARK_DENSE + 64 are ever parked)
+static_assert(RT_PARK_FIELDS * RT_PARK_CAP == RT_PARK_RECORD_DWORDS, "park slice size (rt_device.h) out of step");
 #ifndef RT_PARK_DENSE
 #define RT_PARK_DENSE 48      // lanes that make a shade block worth running while the tile still hands out paths
 #endif
@@ -1102,6 +1119,9 @@ __device__ __forceinline__ bool shade_hit(const PT &P, const HitRec &hit, rt_v3 
 #define RT_PYR_MIN 8
 #endif
 #define RT_STEAL_TRIES  16        // failed joins in a row before a wave retires
+#ifndef RT_PARK_STOP_PATHS
+#define RT_PARK_STOP_PATHS 0      // hits are shaded at once instead of parked when the tile has at most this many paths left to hand out (0: off)
+#endif
 
 // Kernel arguments that are only needed outside the traversal loop (camera, frame and tile bookkeeping, material
 // tables) are read from the kernarg segment WHERE they are used, through a pointer the compiler cannot see through:

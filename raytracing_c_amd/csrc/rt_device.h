@@ -31,6 +31,7 @@
 #define RT_TILE      8       /* work item = 8x8 pixel tile x sample slab */
 #define RT_TILE_PIX  64
 
+#define RT_PARK_RECORD_DWORDS (18 * 128)   /* a wave's slice of RT_KParams.park: RT_PARK_FIELDS x RT_PARK_CAP (rt_dev.hip.h) */
 #define RT_N_COUNTERS 136    /* 0..6 ray counters; 8..23 block statistics of the diagnostic kernel, 24..39 its cycle sums; or 8..135 the
                               * block ledger of the tile-stream kernel (-DRT_LEDGER builds, LG_* slots in rt_dev.hip.h) */
 

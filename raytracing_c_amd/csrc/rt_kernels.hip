@@ -55,12 +55,12 @@
 
 #ifdef RT_LEDGER
 #define RT_LEDGER_WAVES 8192
-__device__ uint32_t g_ledger[RT_LEDGER_WAVES * 64];      // block ledger: one row of LG_* slots per wave (rt_dev.hip.h)
+__device__ uint32_t g_ledger[RT_LEDGER_WAVES * RT_LEDGER_ROW];      // block ledger: one row of LG_* slots per wave (rt_dev.hip.h)
 __global__ void rt_ledger_reduce_kernel(unsigned long long *counters) {
   const int slot = threadIdx.x;
-  if (slot >= LG_N || slot >= 64) return;
+  if (slot >= LG_N || slot >= RT_LEDGER_ROW) return;
   unsigned long long sum = 0ull;
-  for (int w = 0; w < RT_LEDGER_WAVES; w++) sum += g_ledger[w * 64 + slot];
+  for (int w = 0; w < RT_LEDGER_WAVES; w++) sum += g_ledger[w * RT_LEDGER_ROW + slot];
   counters[8 + slot] = sum;
 }
 #endif
@@ -82,13 +82,22 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   const int pyr_off = (n_lds * RT_LDS_NODE_F4 + __builtin_amdgcn_readfirstlane(wave) * (perm_f4 + 96) + perm_f4 - 16) * 16;
   // (+ 128 bytes: 32 cache entries, direct mapped by node: (node + 1) << 8 | cull mask)
 
+#ifdef RT_LEDGER
+  uint32_t *lg = g_ledger + (size_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave) * RT_LEDGER_ROW;
+  const unsigned long long lg_wave_t0 = __builtin_amdgcn_s_memtime();
+#if RT_LEDGER >= 2
+  unsigned long long lg_drain_t0 = 0ull;
+#endif
+#endif
   if (LDSN) {
+    LGT0();
     const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
     for (int i = threadIdx.x; i < n_lds * 12; i += WAVES * 64) {
       int nd = i / 12, q = i - nd * 12;
       smem[nd * RT_LDS_NODE_F4 + q] = g[i];
     }
     __syncthreads();          // the only workgroup barrier of the kernel; waves are independent afterwards
+    LGT1(LG_CYC_COPY);
   }
 
   acc[lane] = 0ull;
@@ -98,10 +107,6 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   // wave-level counters (scalar registers)
   uint32_t w_paths = 0, w_rays = 0, w_nodes = 0, w_leaves = 0, w_shades = 0, w_bgs = 0, w_tex = 0;
   const unsigned long long t_wave_start = cold_args()->wave_times ? __builtin_amdgcn_s_memrealtime() : 0ull;   // RT_WAVE_TIMES only
-#ifdef RT_LEDGER
-  uint32_t *lg = g_ledger + (size_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave) * 64;
-  const unsigned long long lg_wave_t0 = __builtin_amdgcn_s_memtime();
-#endif
   uint32_t n_tiles_done = 0;
   unsigned long long t_last_grab = 0ull;
 
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       if (steal_tries >= RT_STEAL_TRIES) break;
       steal_tries += 1;
       LG(LG_JOIN_X, 1);
+      LGT0();
       // two-level scan with agent-scope loads: groups of 64 tiles that still have an open tile (open_groups[g] > 0),
       // then the tiles of one such group.  Start positions differ per wave so that joiners spread over the open tiles.
       RT_KArgs A = cold_args();
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           }
         }
       }
+      LGT1(LG_CYC_JOIN);
       if (tile_idx < 0) break;                      // nothing left to join
     }
 
@@ -432,7 +439,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           const int h = (int)__popcll(mHit), f = (int)__popcll(mIdle);
           const int back = n_parked < f ? n_parked : f;                 // parked hits that fit into idle lanes
           uint32_t *pk = park + (size_t)__builtin_amdgcn_readfirstlane(wave_id) * (RT_PARK_FIELDS * RT_PARK_CAP);    // (scalar base)
-          if (!tile_open || h + back >= RT_PARK_DENSE || n_parked + h > RT_PARK_CAP) {
+          // (the last paths of a tile are not parked: what is parked when the tile closes runs its bounce chain AFTER the chains of
+          // the paths in flight -- the drain of the tile, and of the launch, gets a second chain long; RT_PARK_STOP_PATHS)
+          const bool tile_ending = RT_PARK_STOP_PATHS > 0 &&
+                                   (int)(n_chunks_tile - u_end) * unit_paths + (int)(u_end - u_cur) * unit_paths <= RT_PARK_STOP_PATHS;
+          if (!tile_open || tile_ending || h + back >= RT_PARK_DENSE || n_parked + h > RT_PARK_CAP) {
             if (back > 0) {
               LG(LG_PLOAD_X, 1); LG(LG_PLOAD_L, back);
               LGM("pload_begin");
@@ -530,7 +541,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
                 uint32_t u0 = 0;
                 if (lane == 0) u0 = atomicAdd(&A->tile_next[tile_idx], grab);
                 u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)u0);
-                if (u0 >= n_chunks_tile) { tile_open = false; break; }
+                if (u0 >= n_chunks_tile) {
+                  tile_open = false;
+                  LGD0((int)__popcll(__ballot(phase != PH_NEED || got)) + n_parked);      // (ledger builds: the tile's drain starts here)
+                  break;
+                }
                 u_cur = u0;
                 u_end = u0 + grab < n_chunks_tile ? u0 + grab : n_chunks_tile;
                 // exactly one wave receives the tile's last unit: it closes the tile in the group summary
@@ -647,8 +662,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     }
 
     // ---------------- flush the wave's share of the tile: lane p owns pixel p ----------------
+    LGD1();
     LGM("flush_begin");
     if (took_any) {
+      LGT0();
       LG(LG_FLUSH_X, 1);
       int x = tile_x0 + (lane & 7), y = tile_y0 + (lane >> 3);
       unsigned long long r = acc[lane * 3 + 0], g = acc[lane * 3 + 1], b = acc[lane * 3 + 2];
@@ -667,6 +684,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       if (tile_cost && lane == 0) atomicAdd(&tile_cost[tile_idx], w_rays - rays_before);
       steal_tries = 0;                    // joined (or owned) a tile that had work: keep looking for more
       n_tiles_done += 1;
+      LGT1(LG_CYC_FLUSH);
     }
   }
   RT_KArgs A = cold_args();
@@ -1229,14 +1247,14 @@ static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipSt
     void *sym = nullptr;
     if (n_waves > RT_LEDGER_WAVES) return (int)hipErrorInvalidValue;
     hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_ledger));
-    if (e == hipSuccess) e = hipMemsetAsync(sym, 0, sizeof(uint32_t) * RT_LEDGER_WAVES * 64, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(sym, 0, sizeof(uint32_t) * RT_LEDGER_WAVES * RT_LEDGER_ROW, stream);
     if (e != hipSuccess) return (int)e;
   }
 #endif
   hipLaunchKernelGGL((rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>), dim3((n_waves + WAVES - 1) / WAVES),
                      dim3(WAVES * 64), smem_bytes, stream, *P);
 #ifdef RT_LEDGER
-  hipLaunchKernelGGL(rt_ledger_reduce_kernel, dim3(1), dim3(64), 0, stream, P->counters);
+  hipLaunchKernelGGL(rt_ledger_reduce_kernel, dim3(1), dim3(RT_LEDGER_ROW), 0, stream, P->counters);
 #endif
   return (int)hipGetLastError();
 }

@@ -21,7 +21,7 @@ def main():
     import raytracing_c_amd as rt
     from raytracing_c_amd import ctypes_abi as abi
     from raytracing_c_amd.configs import load_config
-    assert os.path.basename(rt.native.LIB_PATH) in ("librt_hip_diag.so", "librt_hip_v1.so"), rt.native.LIB_PATH
+    assert os.path.basename(rt.native.LIB_PATH) in ("librt_hip_diag.so", "librt_hip_v1.so", "librt_hip_v2.so"), rt.native.LIB_PATH
     assert rt.lib.rt_init(0) == 0, rt.last_error()
     scenes = {}
     for job in jobs:

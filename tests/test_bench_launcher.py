@@ -103,6 +103,8 @@ def test_bench_distributed_pipeline_on_one_gpu(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["n_gpus"] == 1 and out["value"] > 0
+        if env:
+            assert out["distributed"]["world_size"] == 1 and out["distributed"]["backend"] == "nccl" and out["distributed"]["equal"]
         imgs.append(open(png, "rb").read())
     assert imgs[0] == imgs[1] == imgs[2]
 
@@ -122,4 +124,29 @@ def test_bench_two_ranks_on_one_gpu_deliver_the_same_frame(tmp_path):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and "two streams" in out["config"]["partition"]
+    assert open(one, "rb").read() == open(two, "rb").read()
+    d = out["distributed"]                               # bench.py's own check of the gathered frame against a one-rank render
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["equal"] and d["image_sha256"] == d["one_rank_image_sha256"]
+
+
+def _physical_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif("_physical_gpus() < 2", reason="needs two physical GPUs")
+def test_bench_two_ranks_on_two_gpus_over_rccl(tmp_path):
+    """Switches itself on when the box has two GPUs: `python bench.py --gpus 2` as the driver runs it -- one
+    rank per GPU, the tile gather over RCCL / xGMI.  The line must say world 2 / nccl and carry the hash check; rank 0's frame is
+    the single-GPU frame byte for byte."""
+    common = ("--steps", "3", "--warmup", "1", "--samples", "24", "--no-cpu-baseline", "--no-bvh-compare")
+    one, two = str(tmp_path / "one.png"), str(tmp_path / "two.png")
+    r = _run(*common, "--save", one)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _run("--gpus", "2", *common, "--save", two)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = out["distributed"]
+    assert out["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "nccl" and d["equal"]
     assert open(one, "rb").read() == open(two, "rb").read()

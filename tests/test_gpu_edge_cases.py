@@ -329,3 +329,22 @@ def test_textures_whose_size_is_not_a_multiple_of_the_tile(rt, oracle, diag, tw,
     got = rt.render_frame(hs, w, h, s, b, want_accum=True)
     assert np.array_equal(got["accum"], _oracle.render(hs, w, h, s, b)["accum"])
     assert not np.array_equal(got["accum"], first["accum"])
+
+
+@pytest.mark.parametrize("k", [300.0, 1e5])
+def test_scene_far_from_the_origin_renders_through_the_exact_slab_form(rt, oracle, k):
+    """Deviation D9 has a domain (include/rt_math.h: RT_SLAB_FUSED_MAX_ORIGIN): rays whose origin is 256 units or more from
+    the origin take the reference's (plane - o) * inv on the GPU like in the oracle -- every node block of this frame is the
+    exact kind, no sky loop, no pyramid culling -- and the frame still equals the oracle's bit for bit."""
+    from tests import _oracle
+    from tests._far_scene import translated_spheres
+    hs = translated_spheres(k)
+    w, h, s, b = 160, 128, 4, 4
+    want = _oracle.render(hs, w, h, s, b)
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    c, wc = got["counters"], want["counters"]
+    assert (c.rays, c.node_visits, c.leaf_visits, c.shades, c.backgrounds) == \
+        (wc["rays"], wc["node_visits"], wc["leaf_visits"], wc["shades"], wc["backgrounds"])
+    assert c.shades > 1000

@@ -97,6 +97,105 @@ def test_scene_stamp_notices_material_and_pointer_changes(rt, oracle):
     assert np.array_equal(d["accum"], a["accum"])
 
 
+def _move_a_vertex(hs, delta):
+    """In-place edit inside the (large) coordinate block: the second vertex of every seventh triangle slot moves in y -- enough to
+    change 1 500 pixels of the 160 x 128 spheres frame; -delta restores the exact floats (0.3 + y - 0.3 is not relied on: the
+    callers re-upload or invalidate afterwards)."""
+    T = hs.scene.triangles
+    for i in range(0, int(T.len), 7):
+        T.y[1][i] = T.y[1][i] + delta
+
+
+def test_in_place_edit_between_two_multi_device_frames_reaches_every_device(rt, oracle):
+    """ADVICE r04 (medium): every device slot keeps the full fingerprint of ITS OWN copy.  One vertex moves in place between two
+    frames over 3 devices: the second frame must be the edited scene on every tile, not a mix of old and new copies."""
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("spheres")
+    w, h, s, b = 160, 128, 4, 4
+    assert rt.lib.rt_set_devices(3, 1) == 0
+    try:
+        a = rt.render_context(hs, w, h, s, b, n_threads=3)
+        assert np.array_equal(a["image"], _oracle.render(hs, w, h, s, b)["image"])
+        _move_a_vertex(hs, 0.3)
+        want = _oracle.render(hs, w, h, s, b)["image"]
+        assert not np.array_equal(want, a["image"])
+        got = rt.render_context(hs, w, h, s, b, n_threads=3)
+        assert np.array_equal(got["image"], want)
+    finally:
+        _move_a_vertex(hs, -0.3)
+        rt.lib.rt_set_devices(1, 0)
+
+
+def test_edit_seen_by_one_device_frame_does_not_leave_stale_copies_on_the_other_slots(rt, oracle):
+    """The sequence of ADVICE r04: a frame over N devices; an in-place edit; rt_scene_verify() (or a one-device frame) brings
+    slot 0 up to date; the next N-device frame must not accept slot 1 .. N-1's copies of the scene as it was before."""
+    import ctypes as C
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("spheres")
+    w, h, s, b = 160, 128, 4, 4
+    try:
+        for via_verify in (True, False):
+            assert rt.lib.rt_set_devices(3, 1) == 0
+            a = rt.render_context(hs, w, h, s, b, n_threads=3)
+            assert np.array_equal(a["image"], _oracle.render(hs, w, h, s, b)["image"])
+            _move_a_vertex(hs, 0.3)
+            want = _oracle.render(hs, w, h, s, b)["image"]
+            if via_verify:
+                assert rt.lib.rt_scene_verify(C.byref(hs.scene)) == 0       # drops the copy on EVERY device
+            else:
+                assert rt.lib.rt_set_devices(1, 0) == 0                      # a one-device frame in between re-uploads slot 0 only
+                one = rt.render_context(hs, w, h, s, b, n_threads=1)
+                assert np.array_equal(one["image"], want)
+                assert rt.lib.rt_set_devices(3, 1) == 0
+            got = rt.render_context(hs, w, h, s, b, n_threads=3)
+            assert np.array_equal(got["image"], want), via_verify
+            _move_a_vertex(hs, -0.3)
+            rt.lib.rt_scene_invalidate(C.byref(hs.scene))
+    finally:
+        rt.lib.rt_set_devices(1, 0)
+
+
+def _physical_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif("_physical_gpus() < 2", reason="needs two physical GPUs (hipGetDeviceCount() >= 2)")
+@pytest.mark.parametrize("force_staged", [False, True])
+def test_real_devices_give_the_single_device_frame(oracle, diag, force_staged):
+    """Switches itself on the day `pytest -m gpu` runs on a box with more than one GPU (VERDICT r04 #4): N REAL devices behind
+    render_thread_proc (rt_set_devices(n, 0): hipMemcpyPeerAsync over xGMI, or -- forced here -- the staged copy through pinned
+    host memory), byte for byte the one-device frame, counters summed.  Matches driver.c:793-818."""
+    import raytracing_c_amd as rt
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    n_dev = min(_physical_gpus(), 8)
+    hs, _ = load_config("helmet")
+    w, h, s, b = 320, 200, 6, 8
+    want = _oracle.render(hs, w, h, s, b)
+    lib = diag if force_staged else rt.lib                  # peer copies: the PRODUCT library; the staged branch needs the fault switch
+    assert lib.rt_init(0) == 0
+    try:
+        assert lib.rt_set_devices(1, 0) == 0
+        one = rt.render_context(hs, w, h, s, b, n_threads=1, lib=lib)
+        c1 = rt.render.get_counters(lib)
+        assert lib.rt_set_devices(n_dev, 0) == 0
+        assert lib.rt_device_count() == n_dev
+        diag.rt_diag_multi_fault(1 if force_staged else 0, -1)
+        many = rt.render_context(hs, w, h, s, b, n_threads=n_dev, lib=lib)
+        cn = rt.render.get_counters(lib)
+        assert many["finished"] and many["n_threads"] == 0, rt.last_error(lib)
+        assert np.array_equal(one["image"], want["image"])
+        assert np.array_equal(many["image"], one["image"])
+        assert (cn.paths, cn.rays, cn.node_visits, cn.leaf_visits, cn.shades, cn.backgrounds) == \
+            (c1.paths, c1.rays, c1.node_visits, c1.leaf_visits, c1.shades, c1.backgrounds)
+    finally:
+        diag.rt_diag_multi_fault(0, -1)
+        lib.rt_set_devices(1, 0)
+
+
 def test_multi_device_frame_reports_the_slowest_devices_split(rt):
     """VERDICT r03 #5: a frame over N devices reports where its time went (round 3 wiped it to total_ms only)."""
     import ctypes as C

@@ -129,6 +129,30 @@ def test_srgb_curves(oracle):
     assert oracle.oracle_encode_u8(F(7.5)) == 255 and oracle.oracle_encode_u8(F(-1.0)) == 0     # clamp, raytracer.c:702-706
 
 
+def test_srgb_decode_power_is_within_4_ulp_for_every_float_of_its_domain(oracle):
+    """Contract v3 (include/rt_math.h, rt_pow24): pow_f32((x + 0.055) / 1.055, 2.4) of common.h:84-91 through a degree-6
+    polynomial in the mantissa times one of six constants.  Pinned against the power in double for EVERY float b in
+    [2^-5, 2) -- the six binades a texture sample can reach -- by choosing x so that (x + 0.055f) / 1.055f visits them: here
+    every x = b * 1.055f - 0.055f on a stride of 5 mantissa steps (10 M values; the C sweep of all 50 M gave 3.63 ulp worst,
+    profiles/r05_pow24.md), and the decode of all 256 x 4 u8-lerp corner values exactly as a texture yields them."""
+    from tests import _oracle
+    bits = np.arange(np.float32(2.0 ** -5).view(np.uint32), np.float32(2.0).view(np.uint32), 5, dtype=np.uint32)
+    b = bits.view(F)
+    x = (b * F(1.055) - F(0.055)).astype(F)
+    got = _oracle.math(7, x).astype(np.float64)
+    bb = ((x + F(0.055)).astype(F) / F(1.055)).astype(F).astype(np.float64)          # the b the decode really saw
+    rel = np.abs(got / bb ** 2.4 - 1.0)
+    assert rel.max() < 4 * 2.0 ** -24, rel.max() / 2.0 ** -24
+    u8 = (np.arange(256, dtype=F) / F(255.999)).astype(F)
+    lin = _oracle.math(7, u8).astype(np.float64)
+    want = ((u8.astype(np.float64) + np.float64(F(0.055))) / np.float64(F(1.055))) ** 2.4
+    assert np.max(np.abs(lin / want - 1.0)) < 6 * 2.0 ** -24      # (+ 2.4 x the two roundings of (x + 0.055f) / 1.055f)
+    assert _oracle.math(7, np.array([0.9999999], F))[0] <= 1.0 and _oracle.math(7, np.array([1.0], F))[0] == F(1.0)
+    # outside the core domain (no texture gets there) the general power answers: 0 for b <= 0 and NaN, finite above 2
+    out = _oracle.math(7, np.array([-1.0, -0.055, np.nan, 3.0, -0.03], F))
+    assert out[0] == 0 and out[1] == 0 and out[2] == 0 and abs(out[3] / ((3.055 / 1.055) ** 2.4) - 1) < 3e-6 and out[4] > 0
+
+
 # --- raytracer.c:190-230 ------------------------------------------------------------------
 
 def np_slab(o, d, mn, mx, t_min, t_max):
