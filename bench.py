@@ -241,7 +241,8 @@ LDS_PEAK_GBS = 256 * 128 * MAX_CLOCK_HZ / 1e9           # 128 B / clk / CU
 FP32_VECTOR_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz
 
 
-def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_name, kernel_ms_source, profile_scale=1.0):
+def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_name, kernel_ms_source, profile_scale=1.0,
+                   skipped_root_visits=None):
     """SURVEY 8d prices a ray at 200 flop per node visit + 480 per leaf visit.  The scene is cache resident (the 8d HBM byte
     model gives a rate ABOVE the HBM peak: listed under `algorithmic`, labelled), and there is no dense contraction for
     MFMA, so the roof this path can be priced against is the fp32 VECTOR peak -- `frac` = algorithmic flops / launch time /
@@ -262,7 +263,11 @@ def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_na
            "traffic": None, "kernel": variant_name, "launches_averaged": int(n_launches), "kernel_ms": kernel_ms,
            "kernel_ms_source": kernel_ms_source,
            "flops": {"per_ray": flops_per_ray, "per_launch": flops,
-                     "model": "SURVEY 8d: 200 x node visits + 480 x leaf visits, counters from the kernel"},
+                     "model": "SURVEY 8d: 200 x node visits + 480 x leaf visits, counters from the kernel (equal to the oracle's). "
+                              "FOOTNOTE: `culled_root_visits` of the node visits are COUNTED BUT NOT EXECUTED -- the one root visit of "
+                              "every camera path whose 8x8 tile's pixel pyramid misses every child of the root; the reference spends "
+                              "it (raytracer.c:459-472), the kernel proves its outcome per tile and skips it.  A flops-model fraction "
+                              "is flattered by that share (`culled_flops_share`); `frac_executed_only` removes it"},
            "peak_note": "fp32 vector peak; MFMA does not apply (branchy fp32, no contraction), the HBM byte model of SURVEY 8d "
                         "is served on chip (see algorithmic.ratio_to_hbm_peak)",
            "algorithmic": {"bytes_per_ray": b_ray, "bytes_per_launch": alg_bytes,
@@ -279,6 +284,13 @@ def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_na
            "l1_l2": {"bytes_per_launch": alg_bytes - node_bytes,
                      "rate_GBps": (alg_bytes - node_bytes) / ksec / 1e9 if ksec else None,
                      "note": "leaf tiles, shading records, texels through L1 / L2"}}
+    if skipped_root_visits is not None:
+        culled = float(skipped_root_visits) / max(tot.rays, 1) * rays_per_launch
+        out["flops"]["culled_root_visits"] = culled
+        out["flops"]["culled_flops_share"] = 200.0 * culled / flops if flops else None
+        out["flops"]["culled_share_of_rays"] = culled / rays_per_launch if rays_per_launch else None
+        out["flops"]["executed_node_visits"] = tot.node_visits / rays * rays_per_launch - culled
+        out["frac_executed_only"] = (flops - 200.0 * culled) / ksec / 1e12 / FP32_VECTOR_PEAK_TFLOPS if ksec else None
     if prof and ksec:
         t, fname, stale = prof
         out["replayed_from"] = f"profiles/{fname}"
@@ -615,9 +627,12 @@ def main():
         last_ms = float(rt.lib.rt_kernel_timing_mean_ms(C.byref(n_launches)))
         kernel_ms_source = "2 launches on ONE stream after the timed region (the timed region overlaps consecutive frames' kernels)"
     cnt = rt.render.get_counters()
+    skipped = C.c_uint64(0)
+    if rt.lib.rt_get_skipped_root_visits(C.byref(skipped)) != 0:
+        raise RuntimeError(rt.last_error())
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     stats = torch.tensor([cnt.paths, cnt.rays, cnt.node_visits, cnt.leaf_visits, cnt.shades, cnt.backgrounds,
-                          cnt.textured], dtype=torch.int64, device=dev)
+                          cnt.textured, int(skipped.value)], dtype=torch.int64, device=dev)
     kms = torch.tensor([last_ms], dtype=torch.float64, device=dev)
     if dist is not None:
         if backend != "nccl":
@@ -626,7 +641,8 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    tot = rt.render.Counters(*[int(v) for v in stats.tolist()])
+    tot = rt.render.Counters(*[int(v) for v in stats.tolist()[:7]])
+    skipped_total = int(stats.tolist()[7])
     last_ms = float(kms.item())
 
     # N > 1: what rank 0 holds after the gather must BE the frame -- the same bytes as one rank rendering every chunk (per-path
@@ -692,7 +708,8 @@ def main():
             "kernel_ms": last_ms,
             "roofline": roofline_block(tot, rays_per_launch, last_ms, n_launches.value, prof, pipeline, kernel_ms_source,
                                        profile_scale=(rays_per_launch / prof[0]["rays_per_launch"])
-                                       if prof and world > 1 and prof[0].get("rays_per_launch") else 1.0),
+                                       if prof and world > 1 and prof[0].get("rays_per_launch") else 1.0,
+                                       skipped_root_visits=skipped_total),
         }
         if world == 1 and not args.no_bvh_compare:
             out["config"]["bvh"]["sah"] = bvh_compare(rt, abi, args, cfg, host_images[(frame_no[0] - 1) & 1].numpy())

@@ -72,8 +72,14 @@ extern void             rt_scene_invalidate(Scene const *scene);
  *     leaf tiles) instead of the whole scene being uploaded again, and the stamps are refreshed: also the way to get a
  *     single-texel edit seen that the 1-in-61 sampling of (2) can miss.  Returns 0 = patched in place, 1 = not a patchable
  *     range (the copies were dropped, the next frame uploads), -1 = error.
- * rt_scene_invalidate() drops the cached copies; rt_scene_verify() is the comparison of (2) on demand: 1 = the cached copy
- * still matches the host scene, 0 = it did not (dropped; the next frame uploads), -1 = nothing cached for this Scene. */
+ *     A copy is patched only if the blocks that differ from what it was made from are the one(s) the range lies in; a block that
+ *     changed without a word drops the copy instead (1) -- the unreported edit is not absorbed into the new reference.
+ * Every device keeps the fingerprint of ITS OWN copy: a frame over N devices is checked device by device, so a copy that one
+ * device made before an edit cannot pass because another device has been brought up to date since.
+ * rt_scene_invalidate() drops the cached copies on every device (and a rt_scene_set_static() opt-out: a Scene rebuilt at the same
+ * address starts checked); rt_scene_verify() is the comparison of (2) on demand, for every device: 1 = every cached copy still
+ * matches the host scene, 0 = one did not (the stale ones are dropped; the next frame uploads), -1 = nothing cached on the
+ * primary device for this Scene. */
 extern int              rt_scene_verify(Scene const *scene);
 extern int              rt_scene_touch(Scene const *scene, void const *begin, size_t bytes);
 extern void             rt_scene_set_static(Scene const *scene, i32 is_static);
@@ -171,6 +177,10 @@ extern int rt_render_frame(Scene const *scene, Image const *image, isize samples
 /* Counters of the last rt_render_accumulate / rt_render_frame on this process
  * (read back synchronously; summed over the devices of a multi-device frame). */
 extern int rt_get_counters(RT_Counters *out);
+/* Of node_visits of the last rt_render_accumulate launch (single device): the visits that were counted but not executed -- the
+ * ONE root visit of every camera path whose 8x8 tile's pixel pyramid misses every child box of the root (raytracer.c:459-472
+ * finds no candidate for any of them; the kernel proves that per tile and skips the block).  The oracle counts them too. */
+extern int rt_get_skipped_root_visits(u64 *out);
 
 /* Where the time of the last frame behind render_thread_proc / render / rt_render_frame went, in milliseconds.
  * Host clock: stamp = the per-frame scene check, upload = the scene upload when one was needed, enqueue = launching the
@@ -197,8 +207,9 @@ extern f32 rt_last_kernel_ms(void);
 extern void rt_kernel_timing_reset(void);
 extern f32  rt_kernel_timing_mean_ms(i32 *n_launches);
 
-/* Numeric contract the library's kernels were built with (include/rt_math.h): 2 = explicit fused multiply-add (the
- * product), 1 = -DRT_MATH_NO_FMA (librt_hip_v1.so, the A/B partner).  The CPU checker must be built for the same one. */
+/* Numeric contract the library's kernels were built with (include/rt_math.h): 3 = explicit fused multiply-add + rt_pow24() in
+ * the sRGB decode (the product), 2 = -DRT_MATH_V2 (round 4's arithmetic, librt_hip_v2.so), 1 = -DRT_MATH_NO_FMA (round 3's,
+ * librt_hip_v1.so) -- the A/B partners.  The CPU checker must be built for the same one. */
 extern int rt_math_contract(void);
 
 /* Unit-level device entry points (rt_test_*), the wavefront pipeline switch and the kernel-generation knobs live in the

@@ -1,6 +1,6 @@
 /* oracle.c -- CPU restatement of the reference render path.  TEST INFRASTRUCTURE,
  * see oracle.h for who may use it, the "parity unpinned" statement and the list
- * of deviations D1-D6.  Every function names the reference lines it follows.
+ * of deviations D1-D9.  Every function names the reference lines it follows.
  *
  * Build: see oracle/Makefile (-O2 -ffp-contract=off, no fast-math: the results
  * must be bit-identical to the gfx950 kernels, which share include/rt_math.h).

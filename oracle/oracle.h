@@ -13,7 +13,9 @@
  *   D2 exact 1/sqrt instead of _mm256_rsqrt_ps for primary directions;
  *   D3 depth-0 BVH tests leaf group 0 instead of reading nodes[0];
  *   D4 asin argument clamped to [-1,1] in the background lookup;
- *   D5 no FMA contraction anywhere; libm replaced by include/rt_math.h;
+ *   D5 libm / codin math replaced by include/rt_math.h: no IMPLICIT contraction anywhere, the explicit fused multiply-adds
+ *      of numeric contract v2, and since contract v3 (round 5) rt_pow24() as the power of the sRGB decode (common.h:84);
+ *      -DRT_MATH_NO_FMA / -DRT_MATH_V2 build the checker under contracts v1 / v2 (liboracle_v1.so, liboracle_v2.so);
  *   D6 default accumulation is order-free 32.32 fixed point (rt_math.h);
  *      ORACLE_ACCUM_F32 reproduces the reference's fp32 running sum;
  *   D7 (builder, rt_scene_build.c) stable merge sort, early-leaf chain;
@@ -24,6 +26,9 @@
  *      (if codin's PI is a double), common.h:37 `1.0 / sqrt_f32(lensq)` (lightmap only).  driver.c:133 `2.0`,
  *      :241 `0.5 * (1.0 + Vh.z)`, :416 `0.5` and common.h:84 `2.4` give the same f32 either way.  The GPU kernels
  *      have no fp64 on the path; the difference is below 1 ulp per expression.
+ *   D9 (contract v2 on) the slab distances of a NaN-free ray whose origin components are all below 256 are
+ *      fma(plane, inv, -(o * inv)) instead of (plane - o) * inv (raytracer.c:203-208): rt_slab_fast(), rt_math.h, shared
+ *      with the kernels; the origin bound (round 5) keeps the fused form's plane placement error below 0.153 EPSILON.
  *
  * ORACLE_LITERAL (Oracle_Config.literal = 1) switches D1, D2, D6 and D8 back to the reference's literal semantics:
  * ONE thread whose RNG state is seeded once (frame seed in place of time_now(), raytracer.c:597) and runs on across

@@ -1696,7 +1696,8 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
         (void)hipFree(d->park);
         d->park = nullptr;
         d->park_waves = 0;
-        HIP_TRY(hipMalloc(&d->park, (size_t)grid_waves * RT_PARK_RECORD_DWORDS * 4));
+        const size_t slice_bytes = (size_t)RT_PARK_RECORD_DWORDS * 4;      // a wave's slice: 18 fields x 128 records (rt_device.h)
+        HIP_TRY(hipMalloc(&d->park, (size_t)grid_waves * slice_bytes));
         d->park_waves = grid_waves;
       }
       K.park = d->park;
@@ -2226,6 +2227,21 @@ extern "C" int rt_get_frame_timing(RT_Frame_Timing *out) {
   out->gpu_copy_ms = D.timing.gpu_copy_ms; out->total_ms = D.timing.total_ms;
   out->verify_ms = D.timing.verify_ms; out->gather_ms = D.timing.gather_ms;
   out->n_devices = D.timing.n_devices; out->slowest_device = D.timing.slowest_device;
+  return 0;
+}
+
+static int read_counters(Device &D, unsigned long long c[RT_N_COUNTERS]);
+// Of the node visits of the last rt_render_accumulate launch: how many were COUNTED but not executed -- the one root visit of
+// every camera path whose tile's pixel pyramid misses every child of the root (the reference, and the oracle, spend and count
+// it; the kernel proves its outcome per tile and skips it).  bench.py's roofline carries it as a footnote.
+extern "C" int rt_get_skipped_root_visits(u64 *out) {
+  if (!out) return rt_fail("rt_get_skipped_root_visits: NULL");
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ensure_device(D) != 0) return -1;
+  unsigned long long c[RT_N_COUNTERS];
+  if (read_counters(D, c) != 0) return -1;
+  *out = c[7];
   return 0;
 }
 

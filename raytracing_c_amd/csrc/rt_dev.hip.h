@@ -39,6 +39,7 @@
 #define CNT_SHADES 4
 #define CNT_BG 5
 #define CNT_TEXTURED 6
+#define CNT_SKIPPED_ROOT 7   // of CNT_NODES: root visits of camera paths whose tile's pyramid misses the root -- counted, not executed
 
 struct Ray3 {
   rt_v3 o, d;

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 
 #ifndef RT_NO_SKY_LOOP
     // ================= tiles whose pyramid misses every child of the root: a loop of their own =================
-    // Every camera ray of such a tile (82 % of the camera paths of config #3) costs one node visit that finds no candidate and
+    // Every camera ray of such a tile (56 % of the camera paths of config #3: 299 M of 531 M) costs one node visit that finds no candidate and
     // goes to the environment -- no traversal state, no phases, no parking, no RNG draw.  The loop below does exactly that for
     // batches of up to 64 paths: primary ray, environment lookup, sample into the LDS tile; same arithmetic, same counters as
     // the general loop, which takes over at once -- from the same unit, nothing consumed -- should a ray turn up that is not
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
       SP.tris = nullptr; SP.mats = nullptr; SP.textures = A->textures; SP.texels = A->texels;
       SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
       uint32_t *tile_next = A->tile_next, *open_groups = A->open_groups;
+      uint32_t n_sky = 0;                 // paths served here: their root visit is COUNTED (like the oracle's) but not executed
       for (;;) {
         if (c_next >= c_end) {
           if (u_cur + 1u < u_end) {
@@ -390,11 +391,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
           nv += (uint32_t)__popcll(__ballot(valid[q]));
         }
         w_paths += nv; w_rays += nv; w_nodes += nv; w_bgs += nv;      // (the skipped root visit counts, as in the general loop)
+        n_sky += nv;
         LG(LG_SKY_X, 1); LG(LG_SKY_L, nv);
         c_next += take;
         LGT1(LG_CYC_SKY);
         LGM("sky_end");
       }
+      // counters[CNT_SKIPPED_ROOT]: node visits that are counted but not executed (bench.py's roofline footnote)
+      if (n_sky != 0u && lane == 0) atomicAdd(cold_args()->counters + CNT_SKIPPED_ROOT, (unsigned long long)n_sky);
     }
 #endif
 
@@ -639,7 +643,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         }
         LGM("start_end");
         w_rays += (uint32_t)__popcll(__ballot(start));
-        w_nodes += (uint32_t)__popcll(__ballot(skip_root));
+        {
+          const uint32_t n_skip = (uint32_t)__popcll(__ballot(skip_root));
+          w_nodes += n_skip;
+          if (n_skip != 0u && lane == 0) atomicAdd(cold_args()->counters + CNT_SKIPPED_ROOT, (unsigned long long)n_skip);   // (rare: a sky tile outside the sky loop)
+        }
         LGM("s_end");
         LGT1(LG_CYC_S);
       }

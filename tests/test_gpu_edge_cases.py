@@ -348,3 +348,24 @@ def test_scene_far_from_the_origin_renders_through_the_exact_slab_form(rt, oracl
     assert (c.rays, c.node_visits, c.leaf_visits, c.shades, c.backgrounds) == \
         (wc["rays"], wc["node_visits"], wc["leaf_visits"], wc["shades"], wc["backgrounds"])
     assert c.shades > 1000
+
+
+def test_skipped_root_visits_are_reported(rt, oracle):
+    """bench.py's roofline footnote: of the node visits the kernel reports (equal to the oracle's), rt_get_skipped_root_visits()
+    says how many were counted without being executed -- the root visit of camera paths whose whole 8x8 tile sees only sky."""
+    import ctypes as C
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    from tests._far_scene import translated_spheres
+    hs, _ = load_config("spheres")
+    w, h, s, b = 256, 256, 4, 4
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    want = _oracle.render(hs, w, h, s, b)
+    assert np.array_equal(got["accum"], want["accum"]) and got["counters"].node_visits == want["counters"]["node_visits"]
+    n = C.c_uint64(0)
+    assert rt.lib.rt_get_skipped_root_visits(C.byref(n)) == 0, rt.last_error()
+    assert 0 < n.value < w * h * s and n.value % s == 0            # whole pixels of whole tiles, not the whole frame
+    assert n.value <= got["counters"].backgrounds and n.value <= got["counters"].node_visits
+    far = translated_spheres(1e5)                                   # no ray of this frame may take the shortcut (include/rt_math.h, D9's domain)
+    rt.render_frame(far, 64, 64, 2, 2)
+    assert rt.lib.rt_get_skipped_root_visits(C.byref(n)) == 0 and n.value == 0
