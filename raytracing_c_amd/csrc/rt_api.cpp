@@ -29,7 +29,7 @@
 
 // launchers in rt_kernels.hip
 extern "C" {
-int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream);
+int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, int wg_waves, hipStream_t stream);
 int rt_launch_prepare(int n_tiles, uint32_t *tile_next, uint32_t *open_groups, unsigned long long *counters, uint32_t *work_head,
                       uint32_t *cost_cur, const uint32_t *cost_prev, uint32_t *order, hipStream_t stream);
 int rt_launch_resolve(int width, int height, int samples, int chunks_x, const int32_t *local_chunks, int n_local_chunks,
@@ -1579,8 +1579,10 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
 #endif
 
   // persistent grid: 16 waves per CU (4 per SIMD at <= 128 VGPRs), never more waves than work items
-  int waves_per_cu = knob_int("RT_WAVES_PER_CU", 16);
-  if (waves_per_cu <= 0) waves_per_cu = 16;
+  int waves_per_cu = knob_int("RT_WAVES_PER_CU", 0);
+  const bool waves_per_cu_default = waves_per_cu <= 0;
+  if (waves_per_cu_default) waves_per_cu = 16;
+  int wg_waves = 16;                 // waves per workgroup of the tile-stream kernel: 8 / 12 / 16, chosen below
   int n_waves = D.num_cus * waves_per_cu;
   if (n_waves > K.n_work && K.n_work > 0) n_waves = K.n_work;
   K.sched_thresh = knob_int("RT_SCHED_THRESH", 48);
@@ -1594,7 +1596,25 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
   if (variant == 2) {
     smem = 4 * per_wave;
   } else if (variant != 1) {
-    const int waves_per_block = 16;
+    // Workgroup size by the size of the launch (round 5, profiles/r05_small_launch.md section 3).  A launch ends with every wave
+    // running the bounce chains of its last paths on thinning lanes, and at four waves per SIMD those thin waves are ISSUE-bound:
+    // with two waves per SIMD a bounce of such a chain takes half the time.  A launch with little work per wave slot is mostly
+    // that tail -- config #1: 0.58 ms with 16-wave workgroups, 0.41 with 8 -- one with much work needs all four waves per SIMD
+    // for its body (the driver's default frame: 2.60 / 2.89 / 3.48 ms with 16 / 12 / 8).  One workgroup per CU either way (the
+    // tree fills the LDS).  Measured crossovers, in wave-fulls of paths per slot of the 16-wave grid: tower 640x360x16 (14) 0.91 /
+    // 0.76 / 0.69 ms, spheres 512^2 x 16 (16) 0.83 / 0.74 / 0.75, helmet 512^2 x 16 (16) 1.23 / 1.17 / 1.41, 64 and more: 16 wins.
+    int waves_per_block = 16;
+    if (variant == 5) {
+      const int64_t paths = (int64_t)K.n_local_chunks * 1024 * (int64_t)(K.sample_end - K.sample_first);
+      const int64_t per_slot = paths / ((int64_t)D.num_cus * 16 * 64);
+      waves_per_block = per_slot < 12 ? 8 : (per_slot < 40 ? 12 : 16);
+      const int v = knob_int("RT_WG_WAVES", 0);
+      if (v == 8 || v == 12 || v == 16) waves_per_block = v;
+      if (waves_per_cu_default) waves_per_cu = waves_per_block;
+      n_waves = D.num_cus * waves_per_cu;
+      if (n_waves > K.n_work && K.n_work > 0) n_waves = K.n_work;
+    }
+    wg_waves = waves_per_block;
     int room = (lds_limit - waves_per_block * per_wave) / 208;
     if (room < 0) room = 0;
     K.n_lds_nodes = d->n_nodes < room ? d->n_nodes : room;
@@ -1691,7 +1711,7 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     // hits parked until a dense shade block can be made of them: RT_PARK_RECORD_DWORDS = 18 fields x 128 records per wave
     K.park = nullptr;
     if (!wavefront && knob_int("RT_PARK", 1) != 0 && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
-      const int grid_waves = (n_waves + 15) / 16 * 16;         // whole workgroups of 16 waves are launched
+      const int grid_waves = (n_waves + wg_waves - 1) / wg_waves * wg_waves;         // whole workgroups are launched
       if (d->park_waves < grid_waves) {
         (void)hipFree(d->park);
         d->park = nullptr;
@@ -1737,7 +1757,7 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
   } else
 #endif
   {
-    int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, stream);
+    int rc = rt_launch_path_kernel(&K, n_waves, variant, smem, wg_waves, stream);
     if (rc != 0) return rt_fail("path kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   }
   HIP_TRY(hipEventRecord(D.ws.ev1[slot], stream));

@@ -1277,11 +1277,19 @@ extern "C" int rt_launch_path_kernel_diag(const RT_KParams *P, int n_waves, int 
 extern "C" int rt_math_contract(void) { return RT_MATH_CONTRACT; }      // include/rt_math.h: 2 = explicit FMA, 1 = -DRT_MATH_NO_FMA
 
 // variant 5 = the tile-stream kernel, the only path kernel of the product library; 1-4 exist in the diagnostic build only
-extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, hipStream_t stream) {
+// `wg_waves` = waves per workgroup, 8 / 12 / 16 (one workgroup per CU: 2 / 3 / 4 waves per SIMD), chosen by rt_api.cpp from the size
+// of the launch; the same kernel source, three instances of its launch geometry.
+extern "C" int rt_launch_path_kernel(const RT_KParams *P, int n_waves, int variant, int smem_bytes, int wg_waves, hipStream_t stream) {
 #ifdef RT_DIAG_VARIANTS
   if (variant >= 1 && variant <= 4) return rt_launch_path_kernel_diag(P, n_waves, variant, smem_bytes, stream);
 #endif
   (void)variant;
+  if (wg_waves == 8)
+    return P->short_div ? launch_stream<8, true, RT_STREAM_MINW, true>(P, n_waves, smem_bytes, stream)
+                        : launch_stream<8, true, RT_STREAM_MINW, false>(P, n_waves, smem_bytes, stream);
+  if (wg_waves == 12)
+    return P->short_div ? launch_stream<12, true, RT_STREAM_MINW, true>(P, n_waves, smem_bytes, stream)
+                        : launch_stream<12, true, RT_STREAM_MINW, false>(P, n_waves, smem_bytes, stream);
   return P->short_div ? launch_stream<16, true, RT_STREAM_MINW, true>(P, n_waves, smem_bytes, stream)
                       : launch_stream<16, true, RT_STREAM_MINW, false>(P, n_waves, smem_bytes, stream);
 }

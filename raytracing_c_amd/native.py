@@ -124,7 +124,8 @@ def _declare(d):
     d.rt_untile.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     d.rt_render_frame.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, vp, vp]
     d.rt_get_counters.argtypes = [P(abi.RT_Counters)]
-    d.rt_get_skipped_root_visits.argtypes = [P(C.c_uint64)]
+    if hasattr(d, "rt_get_skipped_root_visits"):           # (absent from older builds that tools/exp_small_ab.sh loads as A/B partners)
+        d.rt_get_skipped_root_visits.argtypes = [P(C.c_uint64)]
     d.rt_math_contract.restype = C.c_int
     d.rt_last_kernel_ms.restype = C.c_float
     d.rt_kernel_timing_reset.restype = None

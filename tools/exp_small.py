@@ -35,7 +35,14 @@ JOBS = [("driver default frame", "helmet", 1024, 1024, 16, 8, 0, 1),
         ("1024^2 x 64 spp", "helmet", 1024, 1024, 64, 8, 0, 1),
         ("1024^2 x 256 spp", "helmet", 1024, 1024, 256, 8, 0, 1),
         ("config #2", "quad", 512, 512, 64, 4, 0, 1),
-        ("config #3", "helmet", 1920, 1080, 256, 8, 0, 1)]
+        ("config #3", "helmet", 1920, 1080, 256, 8, 0, 1),
+        # (only with RT_SMALL_JOBS: frames between config #1 and the default frame, for the workgroup-size crossover)
+        ("helmet 256x144 x 16", "helmet", 256, 144, 16, 8, 0, 1),
+        ("helmet 512^2 x 16", "helmet", 512, 512, 16, 8, 0, 1),
+        ("helmet 512^2 x 64", "helmet", 512, 512, 64, 8, 0, 1),
+        ("spheres 512^2 x 16", "spheres", 512, 512, 16, 4, 0, 1),
+        ("tower 640x360 x 16", "tower", 640, 360, 16, 12, 0, 1)]
+EXTRA = 5
 
 
 def main():
@@ -50,6 +57,8 @@ def main():
     scenes = {}
     for (label, name, w, h, s, b, rank, world) in JOBS:
         if only and label not in only.split(";"):
+            continue
+        if not only and label in [j[0] for j in JOBS[-EXTRA:]]:
             continue
         if name not in scenes:
             hs, _ = load_config(name)
