@@ -20,6 +20,7 @@ VARIANT_JOBS = [dict(config=name, w=w, h=h, s=s, b=b, env={"RT_KERNEL": str(v)},
 KNOBS = [{"RT_SCHED_THRESH": "1"}, {"RT_SCHED_THRESH": "64"}, {"RT_LDS_NODES": "9"}, {"RT_LDS_NODES": "0"}, {"RT_WAVES_PER_CU": "1"},
          {"RT_ORDER": "identity"}, {"RT_GRAB": "1"}, {"RT_GRAB": "4"}, {"RT_DRAIN_THRESH": "1"}, {"RT_PYRAMID": "0"},
          {"RT_SHORT_DIV": "0"}, {"RT_PARK": "0"}, {"RT_KERNEL": "3", "RT_SCHED_THRESH": "16"},
+         {"RT_WG_WAVES": "8"}, {"RT_WG_WAVES": "12"}, {"RT_WG_WAVES": "16"},      # the three workgroup sizes the product picks from by launch size
          {"RT_PIPELINE": "wf"}, {"RT_PIPELINE": "wf", "RT_WF_GEOMETRY": "1"}, {"RT_PIPELINE": "wf", "RT_WF_GEOMETRY": "2", "RT_LDS_NODES": "40"}]
 KNOB_JOBS = [dict(config="helmet", w=80, h=45, s=5, b=8, env=k, slabs=[0, 1, 4, 64]) for k in KNOBS]
 

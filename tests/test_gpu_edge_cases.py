@@ -369,3 +369,18 @@ def test_skipped_root_visits_are_reported(rt, oracle):
     far = translated_spheres(1e5)                                   # no ray of this frame may take the shortcut (include/rt_math.h, D9's domain)
     rt.render_frame(far, 64, 64, 2, 2)
     assert rt.lib.rt_get_skipped_root_visits(C.byref(n)) == 0 and n.value == 0
+
+
+@pytest.mark.parametrize("w,h,s", [(256, 144, 16), (640, 360, 16), (512, 512, 64)])
+def test_every_workgroup_size_the_library_picks_gives_the_same_frame(rt, oracle, w, h, s):
+    """The path kernel runs with 8-, 12- or 16-wave workgroups depending on the paths per wave slot of the launch (rt_api.cpp:
+    below 12 wave-fulls 8, below 40 twelve, else 16 -- 2 / 14 / 64 for these three frames on a 256-CU chip).  The launch geometry
+    enters no result: each frame equals the oracle's."""
+    from raytracing_c_amd.configs import load_config
+    from tests import _oracle
+    hs, _ = load_config("spheres")
+    want = _oracle.render(hs, w, h, s, 4)
+    got = rt.render_frame(hs, w, h, s, 4, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    c, wc = got["counters"], want["counters"]
+    assert (c.rays, c.node_visits, c.leaf_visits, c.shades) == (wc["rays"], wc["node_visits"], wc["leaf_visits"], wc["shades"])
