@@ -1606,7 +1606,11 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     int waves_per_block = 16;
     if (variant == 5) {
       const int64_t paths = (int64_t)K.n_local_chunks * 1024 * (int64_t)(K.sample_end - K.sample_first);
-      const int64_t per_slot = paths / ((int64_t)D.num_cus * 16 * 64);
+      int64_t per_slot = paths / ((int64_t)D.num_cus * 16 * 64);
+      // (a depth-0 scene -- one leaf group, no node blocks -- traces a ray in a quarter of the instructions: its launches are as
+      //  short as launches a quarter their size; quad 256^2 / 512^2 / 768^2 / 1024^2 x 64 spp: best with 8 / 12 / 12 / 16 waves,
+      //  0.43 / 0.90 / 1.62 / 2.43 ms against 0.59 / 0.99 / 1.67 / 2.43 with 16, gpurun_out/r05s/wg.md)
+      if (K.depth == 0) per_slot /= 4;
       waves_per_block = per_slot < 12 ? 8 : (per_slot < 40 ? 12 : 16);
       const int v = knob_int("RT_WG_WAVES", 0);
       if (v == 8 || v == 12 || v == 16) waves_per_block = v;
