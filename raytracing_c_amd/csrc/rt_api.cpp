@@ -1056,10 +1056,10 @@ static int touch_device_scene(RT_Device_Scene *d, Scene const *scene, const void
   return 0;
 }
 
-// Does [begin, begin + bytes) lie inside block `b`?
+// Does the reported range [begin, begin + bytes) touch block `b`?
 static bool fp_block_holds(const FpBlock &b, const void *begin, size_t bytes) {
-  size_t off;
-  return b.begin && range_in(begin, bytes, b.begin, b.bytes, &off);
+  const uintptr_t r0 = (uintptr_t)begin, r1 = r0 + bytes, b0 = (uintptr_t)b.begin, b1 = b0 + b.bytes;
+  return b.begin && r0 < b1 && b0 < r1;
 }
 
 // 0 = every resident copy was patched in place, 1 = copies were dropped (the next frame uploads), -1 = error

@@ -384,3 +384,32 @@ def test_every_workgroup_size_the_library_picks_gives_the_same_frame(rt, oracle,
     assert np.array_equal(want["accum"], got["accum"])
     c, wc = got["counters"], want["counters"]
     assert (c.rays, c.node_visits, c.leaf_visits, c.shades) == (wc["rays"], wc["node_visits"], wc["leaf_visits"], wc["shades"])
+
+
+def test_scene_touch_does_not_absorb_an_edit_nobody_reported(rt, oracle):
+    """two in-place edits, ONE reported.  rt_scene_touch() compares block fingerprints first: a block that changed and
+    is not the one the reported range lies in means an edit nobody told about -- the copy is dropped (return 1) and the next frame
+    uploads, instead of the unreported edit being taken into the new reference where no later check could find it."""
+    from raytracing_c_amd import ctypes_abi as abi
+    from tests import _oracle
+    hs = _big_textured_quad(256)
+    w, h, s, b = 64, 64, 16, 3
+    first = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(first["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    tex = hs._image_arrays[0]
+    tex[100:140, 100:140] = (255, 255, 255)                       # reported below
+    soa = hs.soa_array()
+    soa[6, :2] -= 0.125                                           # NOT reported: the z of the first vertex of both triangles
+    rc = rt.lib.rt_scene_touch(C.byref(hs.scene), tex[100, 100:].ctypes.data, 40 * tex.shape[1] * 3)
+    assert rc == 1, "a second, unreported edit must drop the copy"
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    want = _oracle.render(hs, w, h, s, b)
+    assert np.array_equal(got["accum"], want["accum"]) and not np.array_equal(want["accum"], first["accum"])
+    t = abi.RT_Frame_Timing()
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0 and t.upload_ms > 0.0
+    # ... and a reported edit alone is patched in place
+    tex[10:12, 10:200] = (0, 0, 0)
+    assert rt.lib.rt_scene_touch(C.byref(hs.scene), tex[10, 10:].ctypes.data, 2 * tex.shape[1] * 3) == 0
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(got["accum"], _oracle.render(hs, w, h, s, b)["accum"])
+    assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0 and t.upload_ms == 0.0
