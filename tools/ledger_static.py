@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_Z21rt_path_kernel_streamILi16ELb1ELi1ELb1EEv10RT_KParams"
+KERNEL = os.environ.get("RT_LEDGER_KERNEL", "_Z21rt_path_kernel_streamILi16ELb1ELi1ELb1EEv10RT_KParams")
 
 
 def kernel_asm(path=None):
@@ -98,8 +98,10 @@ def build_cfg(lines):
 
 def query(blocks, start, stops, field="valu"):
     """Sum of `field` over the basic blocks reachable from marker `start` without entering a block that starts with a marker
-    in `stops` (or with `start` again)."""
-    first = next(b for b in blocks if b.marker == start)
+    in `stops` (or with `start` again).  0 for a marker the kernel instance does not have."""
+    first = next((b for b in blocks if b.marker == start), None)
+    if first is None:
+        return 0
     seen, todo, total = set(), [first], 0
     while todo:
         b = todo.pop()
