@@ -336,7 +336,7 @@ RT_FN float rt_asinf(float x) {
  * 3.7 ulp (2.2e-7 relative) of the true power for EVERY float (all 6 x 2^23 of them compared with pow() in double: 3.63 ulp at
  * worst; tests/test_oracle_kat.py compares every fifth); exp(2.4 log b) of contract v2 was within 1.1e-6.  Outside (and for NaN) rt_pow24() is rt_powf():
  * 0 for b <= 0 or NaN as before.  7 fused multiply-adds / multiplies, 2 integer operations, 5 compare + select pairs. */
-RT_FN float rt_pow24_core(float b) {
+RT_FN float rt_pow24_poly(float b) {               /* P(m - 1.5), m = the mantissa of b as a float in [1, 2) */
   const float t = rt_u2f((rt_f2u(b) & 0x007fffffu) | 0x3f800000u) - 1.5f;
   float p = -1.257556141e-03f;
   p = rt_fmaf(p, t,  3.908345941e-03f);
@@ -345,8 +345,15 @@ RT_FN float rt_pow24_core(float b) {
   p = rt_fmaf(p, t,  1.975808740e+00f);
   p = rt_fmaf(p, t,  4.233884811e+00f);
   p = rt_fmaf(p, t,  2.646177769e+00f);
-  /* 2^(-2.4 n), n = 0 .. 5, rounded to nearest; picked by comparisons with the binade boundaries (a chain of five selects:
-   * written over the bits of the exponent, hipcc turned the select tree into divergent branches) */
+  return p;
+}
+/* 2^(-2.4 n), n = 0 .. 5, rounded to nearest, as a table over the three low bits of b's biased exponent (127 - n = 127 .. 122):
+ * what the path kernel keeps in LDS (rt_dev.hip.h: 2 + 1 instructions instead of the 14 of the selects below) */
+#define RT_POW24_SCALES {0.0f, 0.0f, 2.441406250e-04f, 1.288581989e-03f, 6.801176351e-03f, 3.589682281e-02f, 1.894645691e-01f, 1.0f}
+RT_FN float rt_pow24_core(float b) {
+  const float p = rt_pow24_poly(b);
+  /* picked by comparisons with the binade boundaries (a chain of five selects: written over the bits of the exponent, hipcc
+   * turned the select tree into divergent branches) */
   float s = 1.0f;
   s = (b < 1.0f)     ? 1.894645691e-01f : s;
   s = (b < 0.5f)     ? 3.589682281e-02f : s;

@@ -1589,7 +1589,7 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
   if (K.sched_thresh < 1 || K.sched_thresh > 64) K.sched_thresh = 48;
   // dynamic LDS per workgroup: per wave (perm stack: depth x 256 B, accumulator tile: 1536 B) and as many leading BVH
   // nodes (level order) as fit in the 160 KB of a CU at 208 B each
-  const int lds_limit = 160 * 1024;
+  const int lds_limit = 160 * 1024 - 64;      // (- the kernel's static LDS: the 32-byte sRGB scale table, rt_dev.hip.h rt_pow24_lds)
   int per_wave = (K.depth > 0 ? K.depth : 1) * 256 + 1536;
   int smem = 0;
   K.n_lds_nodes = 0;

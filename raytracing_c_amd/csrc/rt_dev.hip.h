@@ -706,6 +706,23 @@ __device__ __forceinline__ rt_v3 tex_bilinear(const PT &P, int tex, float tx, fl
 // the division for every a = x + 0.055f with 2^-104 <= |a| < infinity and for NaN (tools/exp/div_test.hip, all 2^32 a);
 // rt_test_srgb_sweep compares every x in [0, 2] -- 1.07 G bit patterns -- with rt_srgb_to_linear1().  A texture sample is a
 // lerp of u8 / 255.999 values, 0 <= x <= 0.9961, or NaN for NaN texture coordinates.  Same rt_powf() afterwards.
+// POW24_LDS: the scale 2^(-2.4 n) of rt_pow24_core() read from a table in LDS by the exponent of b (RT_POW24_SCALES, rt_math.h;
+// the kernel fills rt_pow24_lds before its first barrier: pow24_lds_init) -- a shift, a mask and a ds_read_b32 for five compares,
+// five selects and four constant moves.  The same constants: the same product.  Asked for through the parameter struct of the
+// caller (Pow24InLds<PT>): only a kernel that fills the table may.
+static __shared__ float rt_pow24_lds[8];
+template <class PT> struct Pow24InLds { static constexpr bool value = false; };
+__device__ __forceinline__ void pow24_lds_init(int tid) {        // before a __syncthreads() of the kernel
+  const float scales[8] = RT_POW24_SCALES;
+  if (tid < 8) {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 2; k < 8; k++) v = (tid == k) ? scales[k] : v;
+    rt_pow24_lds[tid] = v;
+  }
+}
+
+template <bool POW24_LDS = false>
 __device__ __forceinline__ float srgb_to_linear_tex1(float x) {
 #ifdef RT_EXP_SRGB_IEEE
   return rt_srgb_to_linear1(x);
@@ -719,7 +736,9 @@ __device__ __forceinline__ float srgb_to_linear_tex1(float x) {
   // every b in [2^-5, 2), which is every b a texture sample produces; NaN (NaN texture coordinates) and values no u8 texture
   // yields take rt_powf() in a branch the wave skips.  Same bits as rt_srgb_to_linear1() for every x in [0, 2]: rt_test_srgb_sweep.
   const float b = __builtin_fmaf(r, c, q);
-  float p = rt_pow24_core(b);
+  float p;
+  if (POW24_LDS) p = rt_pow24_poly(b) * *reinterpret_cast<const float *>(reinterpret_cast<const char *>(rt_pow24_lds) + (((uint32_t)as_i(b) >> 21) & 28u));
+  else p = rt_pow24_core(b);
   if (!(b >= 0x1p-5f && b < 2.0f)) p = rt_powf(b, 2.4f);
   return p;
 #elif defined(RT_EXP_POW_PLAIN)
@@ -735,8 +754,9 @@ __device__ __forceinline__ float srgb_to_linear_tex1(float x) {
   return (b > 0.0f) ? p : 0.0f;
 #endif
 }
+template <bool POW24_LDS = false>
 __device__ __forceinline__ rt_v3 srgb_to_linear_tex(rt_v3 v) {
-  return rt_v3_make(srgb_to_linear_tex1(v.x), srgb_to_linear_tex1(v.y), srgb_to_linear_tex1(v.z));
+  return rt_v3_make(srgb_to_linear_tex1<POW24_LDS>(v.x), srgb_to_linear_tex1<POW24_LDS>(v.y), srgb_to_linear_tex1<POW24_LDS>(v.z));
 }
 
 // driver.c:95-104
@@ -746,7 +766,7 @@ __device__ __forceinline__ rt_v3 background_lookup(const PT &P, rt_v3 dir) {
   float inv_two_pi = 1.0f / (2.0f * RT_PI);
   float u = rt_madd(rt_atan2f(dir.z, dir.x), inv_two_pi, 0.5f);
   float v = rt_madd(-rt_asinf(dir.y), inv_pi, 0.5f);
-  return srgb_to_linear_tex(tex_bilinear(P, P.bg_texture, u, v));
+  return srgb_to_linear_tex<Pow24InLds<PT>::value>(tex_bilinear(P, P.bg_texture, u, v));
 }
 
 // ---------------------------------------------------------------------------------
@@ -946,7 +966,7 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
   if (RT_TEX_BATCH == 2 && hm) { tm = tex_taps(D[2], in.uvx, in.uvy); qm = tex_fetch(P.texels + D[2].offset, tm); }
   if (RT_TEX_BATCH == 2 && he) { te = tex_taps(D[3], in.uvx, in.uvy); qe = tex_fetch(P.texels + D[3].offset, te); }
   rt_v3 base_color = rt_v3_make(m0.x, m0.y, m0.z);
-  if (ha) base_color = rt_v3_mul(base_color, srgb_to_linear_tex(tex_combine(qa, ta)));
+  if (ha) base_color = rt_v3_mul(base_color, srgb_to_linear_tex<Pow24InLds<PT>::value>(tex_combine(qa, ta)));
 
   float roughness = m0.w, metalness = m1.w;
   if (RT_TEX_BATCH < 2 && hm) { tm = tex_taps(D[2], in.uvx, in.uvy); qm = tex_fetch(P.texels + D[2].offset, tm); }
@@ -961,7 +981,7 @@ __device__ __forceinline__ void shade(const PT &P, int mat, const ShadeIn &in, u
 
   emission = rt_v3_make(m1.x, m1.y, m1.z);
   if (RT_TEX_BATCH < 2 && he) { te = tex_taps(D[3], in.uvx, in.uvy); qe = tex_fetch(P.texels + D[3].offset, te); }
-  if (he) emission = rt_v3_mul(emission, srgb_to_linear_tex(tex_combine(qe, te)));
+  if (he) emission = rt_v3_mul(emission, srgb_to_linear_tex<Pow24InLds<PT>::value>(tex_combine(qe, te)));
 
   // basis(), driver.c:155-164
   rt_v3 t, b;
@@ -1487,6 +1507,9 @@ struct ShadeParams {            // what shade_hit / background_lookup read (same
   const uint32_t *texels;
   int32_t bg_texture, max_bounces;
 };
+
+struct ShadeParamsLds : ShadeParams {};      // ... of a kernel that keeps the sRGB scale table in LDS (pow24_lds_init)
+template <> struct Pow24InLds<ShadeParamsLds> { static constexpr bool value = RT_MATH_POW24 != 0; };
 
 struct PrimaryParams {          // what primary_ray reads
   float cam[3][4];

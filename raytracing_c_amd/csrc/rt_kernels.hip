@@ -89,6 +89,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   unsigned long long lg_drain_t0 = 0ull;
 #endif
 #endif
+  pow24_lds_init((int)threadIdx.x);
   if (LDSN) {
     LGT0();
     const float4 *g = reinterpret_cast<const float4 *>(P.nodes);
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
     }
     __syncthreads();          // the only workgroup barrier of the kernel; waves are independent afterwards
     LGT1(LG_CYC_COPY);
+  } else {
+    __syncthreads();          // (the sRGB scale table)
   }
 
   acc[lane] = 0ull;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
 #pragma unroll
         for (int j = 0; j < 4; j++) PP.cam[i][j] = A->cam[i][j];
       PP.focal_length = A->focal_length; PP.inv_width = A->inv_width; PP.inv_height = A->inv_height; PP.aspect = A->aspect;
-      ShadeParams SP;
+      ShadeParamsLds SP;
       SP.tris = nullptr; SP.mats = nullptr; SP.textures = A->textures; SP.texels = A->texels;
       SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
       uint32_t *tile_next = A->tile_next, *open_groups = A->open_groups;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         rt_v3 radiance = rt_v3_make(0, 0, 0);
         rt_v3 org = ray.o, dir = ray.d;
         RT_KArgs A = cold_args();
-        ShadeParams SP;
+        ShadeParamsLds SP;
         SP.tris = A->tris; SP.mats = A->mats; SP.textures = A->textures; SP.texels = A->texels;
         SP.bg_texture = A->bg_texture; SP.max_bounces = A->max_bounces;
         // ---- environment for the paths that left the scene ----
@@ -1245,8 +1248,9 @@ static int launch_stream(const RT_KParams *P, int n_waves, int smem_bytes, hipSt
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (smem_bytes > 48 * 1024 && (dev >= 32 || !(__atomic_load_n(&attr_devices, __ATOMIC_RELAXED) & (1u << dev)))) {
+    // (dynamic + the kernel's 32 static bytes, rt_pow24_lds, must stay within the 160 KB of a CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rt_path_kernel_stream<WAVES, LDSN, MINW, SHORT_DIV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return (int)e;
     if (dev < 32) __atomic_fetch_or(&attr_devices, 1u << dev, __ATOMIC_RELAXED);
   }
