@@ -1470,9 +1470,19 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
               // not NaN-free -- a lane in a blue moon -- redo it through the min / max form
               const char *nb = reinterpret_cast<const char *>(lds_nodes + lds_node_f4(node)) + j * 4;
               const rt_v3 bs = slab_bias3(ray);
-              const float sx = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + ((as_i(ray.inv_x) >> 31) & 96)), ray.o.x, ray.inv_x, bs.x);
-              const float sy = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + 32 + ((as_i(ray.inv_y) >> 31) & 96)), ray.o.y, ray.inv_y, bs.y);
-              const float sz = rt_slab_t_fast(*reinterpret_cast<const float *>(nb + 64 + ((as_i(ray.inv_z) >> 31) & 96)), ray.o.z, ray.inv_z, bs.z);
+              // the three planes in flight together (left to itself hipcc reuses one register for address and value and waits
+              // for each read before it issues the next: three LDS round trips in the loop that has the fewest lanes to hide them)
+              float px, py, pz;
+              {
+                const uint32_t ax = (uint32_t)(uintptr_t)(nb + ((as_i(ray.inv_x) >> 31) & 96));
+                const uint32_t ay = (uint32_t)(uintptr_t)(nb + ((as_i(ray.inv_y) >> 31) & 96));
+                const uint32_t az = (uint32_t)(uintptr_t)(nb + ((as_i(ray.inv_z) >> 31) & 96));
+                asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4 offset:32\n\tds_read_b32 %2, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(px), "=&v"(py), "=&v"(pz) : "v"(ax), "v"(ay), "v"(az) : "memory");
+              }
+              const float sx = rt_slab_t_fast(px, ray.o.x, ray.inv_x, bs.x);
+              const float sy = rt_slab_t_fast(py, ray.o.y, ray.inv_y, bs.y);
+              const float sz = rt_slab_t_fast(pz, ray.o.z, ray.inv_z, bs.z);
               dj = fmax_hw(RT_EPS, fmax_hw(sx, fmax_hw(sy, sz)));
               LGM("pop_rare_begin");
               if (!ray.fast) dj = slab_entry_child<false>(reinterpret_cast<const float *>(lds_nodes + lds_node_f4(node)) + j, ray);
