@@ -1635,14 +1635,15 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
   const uint32_t *cost_prev = nullptr;
   if (variant != 1 && !knob_is("RT_ORDER", "identity") && K.n_tiles > 0) {
     const int n_tiles = K.n_tiles;
-    // the costs of a launch are reusable by a launch of the same view, partition and bounce limit
+    // the costs of a launch are reusable by a launch of the same frame shape, partition and bounce limit -- NOT only of the same
+    // view: for a camera that moves between frames the previous view's costs are still a better guide than none (helmet, a rotation
+    // of 0.5 / 2 / 10 degrees per frame: -0.7 / -0.8 / -0.2 % kernel time at 256 spp, -2.3 % at 1024^2 x 64 spp against the identity
+    // order, tools/exp_moving.py, profiles/r05_experiments.md section 4), and an order is only ever a schedule, never a pixel
     uint64_t key = 1469598103934665603ull;
     auto mix = [&key](const void *ptr, size_t n) {
       const unsigned char *b = (const unsigned char *)ptr;
       for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; }
     };
-    mix(K.cam, sizeof K.cam);
-    mix(&K.focal_length, sizeof K.focal_length);
     int32_t ids[6] = {K.width, K.height, K.rank, K.world, K.max_bounces, n_tiles};
     mix(ids, sizeof ids);
     if (d->sched_tiles != n_tiles) {
