@@ -1259,6 +1259,89 @@ __device__ __forceinline__ uint32_t node_enter_few(const Ray3 &r, const float4 *
   return w | ((f0 + f1 + f2 + f3) << 24);
 }
 
+// ---- pyramid culling of leaf blocks (tile-stream kernel) ----
+// The camera rays of a wave sit on one or two pixels: most leaf blocks that hold camera rays hold (almost) nothing else, all
+// of them on ONE leaf group (config #3: 6.4 M of 16.8 M leaf blocks, 53 lanes each).  Such a block tests only the triangles the
+// tile's pyramid can touch.  Lane l tests triangle (l & 7) of leaf group g against plane ((l >> 3) & 3); returns the 8-bit mask
+// of the triangles that lie entirely outside one plane -- all three vertices by the relative margin of pyramid_cull_mask() -- :
+// no point of a ray inside the pyramid lies in such a triangle, so the point where the ray meets the triangle's plane has a
+// barycentric coordinate outside [0, 1] by far more than the test's epsilon and ray_triangles_hit_8 reports a miss for it
+// (raytracer.c:84-188), whatever the ray's t_max.  (Vertices b, c are a + (b - a), a + (c - a) here, an ulp off the reference's:
+// the `coarse` term of the margin covers a thousand of those.)
+__device__ __forceinline__ uint32_t pyramid_cull_tris(const float *leaves, const float *pyr, int g) {
+  const int lane = lane_now();
+  const float *tb = leaves + (size_t)g * 72 + (lane & 7);
+  const float *pl = pyr + ((lane >> 3) & 3) * 4;
+  const float ox = pyr[16], oy = pyr[17], oz = pyr[18];
+  const float nx = pl[0], ny = pl[1], nz = pl[2];
+  const float ax = tb[0], e1x = tb[8], e2x = tb[16], ay = tb[24], e1y = tb[32], e2y = tb[40], az = tb[48], e1z = tb[56], e2z = tb[64];
+  bool outside = true;
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    const float vx = v == 0 ? ax : (v == 1 ? ax + e1x : ax + e2x);
+    const float vy = v == 0 ? ay : (v == 1 ? ay + e1y : ay + e2y);
+    const float vz = v == 0 ? az : (v == 1 ? az + e1z : az + e2z);
+    const float px = nx * (vx - ox), py = ny * (vy - oy), pz = nz * (vz - oz);
+    const float val = px + py + pz;                                                   // n . (vertex - o)
+    const float extent = fabsf(px) + fabsf(py) + fabsf(pz);
+    const float coarse = fabsf(nx) * (fabsf(ox) + fabsf(vx)) + fabsf(ny) * (fabsf(oy) + fabsf(vy)) + fabsf(nz) * (fabsf(oz) + fabsf(vz));
+    outside = outside && (val > 1e-3f * extent + 1e-6f * coarse);                     // (NaN compares false: not outside)
+  }
+  const uint32_t m = (uint32_t)__ballot(outside);                                     // lanes 0..31: 4 planes x 8 triangles
+  return (m | (m >> 8) | (m >> 16) | (m >> 24)) & 0xFFu;
+}
+
+// leaf_test_short_div() / leaf_test<false>() of leaf group g (WAVE-UNIFORM) restricted to the triangles in `surv` (wave-uniform):
+// the triangle's nine floats come through the scalar cache, the arithmetic per triangle is tri_test()'s expression for
+// expression, triangles in ascending order with a strict comparison (lowest index wins ties, raytracer.c:27-29).
+template <bool SHORT_DIV>
+__device__ __forceinline__ void tri_test_uniform(const Ray3 &r, rt_v3 a, rt_v3 edge1, rt_v3 edge2, int k, float &best, float &bu, float &bv, int &bi) {
+  rt_v3 rxe2 = rt_v3_cross(r.d, edge2);
+  float det = rt_v3_dot(edge1, rxe2);
+  float inv_det = SHORT_DIV ? rcp_leaf(det) : 1.0f / det;
+  rt_v3 s = rt_v3_sub(r.o, a);
+  rt_v3 sxe1 = rt_v3_cross(s, edge1);
+  float u = inv_det * rt_v3_dot(s, rxe2);
+  float v = inv_det * rt_v3_dot(r.d, sxe1);
+  float t = inv_det * rt_v3_dot(edge2, sxe1);
+  bool miss = (u < -RT_EPS) || (u > 1.0f + RT_EPS) || (v < -RT_EPS) || (u + v > 1.0f + RT_EPS) || (t < RT_EPS);
+  if (SHORT_DIV) {
+    if (!miss && t < best) { best = t; bi = k; bu = u; bv = v; }          // (see leaf_test_short_div)
+  } else {
+    float dist = miss ? RT_INF : t;
+    dist = (dist > 0.0f) ? dist : RT_INF;                                  // NaN -> +inf (min_f32x8)
+    if (dist < best) { best = dist; bi = k; bu = u; bv = v; }
+  }
+}
+template <bool SHORT_DIV>
+__device__ __forceinline__ bool leaf_test_uniform(const RT_KParams &P, const Ray3 &r, int g, uint32_t surv, HitRec &hit) {
+  float best = RT_INF, bu = 0.0f, bv = 0.0f;
+  int   bi = 0;
+  cfloat *lb = as_scalar_ptr(P.leaves) + (size_t)g * 72;
+  // two triangles per trip: their eighteen scalar loads are in flight together (a tile's pyramid leaves two of a group's eight
+  // triangles on average: most blocks are one trip)
+  while (surv) {
+    const int k0 = (int)__builtin_ctz(surv);
+    surv &= surv - 1u;
+    const bool two = surv != 0u;
+    const int k1 = two ? (int)__builtin_ctz(surv) : k0;
+    surv &= surv - 1u;                                                     // (0 & anything = 0)
+    cfloat *t0 = lb + k0, *t1 = lb + k1;
+    const rt_v3 a0 = rt_v3_make(t0[0], t0[24], t0[48]), e10 = rt_v3_make(t0[8], t0[32], t0[56]), e20 = rt_v3_make(t0[16], t0[40], t0[64]);
+    const rt_v3 a1 = rt_v3_make(t1[0], t1[24], t1[48]), e11 = rt_v3_make(t1[8], t1[32], t1[56]), e21 = rt_v3_make(t1[16], t1[40], t1[64]);
+    tri_test_uniform<SHORT_DIV>(r, a0, e10, e20, k0, best, bu, bv, bi);
+    if (two) tri_test_uniform<SHORT_DIV>(r, a1, e11, e21, k1, best, bu, bv, bi);
+  }
+  if (best < hit.t) {
+    hit.t = best;
+    hit.tri = g * 8 + bi;
+    hit.u = bu;
+    hit.v = bv;
+    return true;
+  }
+  return false;
+}
+
 typedef const RT_KParams __attribute__((address_space(4))) *RT_KArgs;
 __device__ __forceinline__ RT_KArgs cold_args() {
   RT_KArgs p = (RT_KArgs)__builtin_amdgcn_kernarg_segment_ptr();      // the RT_KParams block is the kernel's only argument
@@ -1307,6 +1390,40 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
       LG(LG_LEAF_CAM, __popcll(__ballot(phase == PH_LEAF && is_cam)));
 #endif
       w_leaves += (uint32_t)nL;
+#if !RT_LEAF_PAIRS && !defined(RT_NO_LEAF_CULL)
+      // camera rays of this tile about to test the same leaf group, (almost) alone in the block: only the triangles their
+      // pyramid can touch; the other lanes keep waiting for a leaf block
+      bool leaf_done = false;
+      if (PYRAMID && pyr_nodes > 0) {
+        const unsigned long long maskL = __ballot(phase == PH_LEAF);
+        const unsigned long long camL = maskL & __ballot(is_cam);
+        if (camL != 0ull) {
+          const int c0 = __builtin_amdgcn_readlane(child, (int)__builtin_ctzll(camL));
+          const int nG = (int)__popcll(camL & __ballot(child == c0));
+          const int g0 = c0 - P.last_row_offset;
+          if (nG * RT_PYR_DEN >= nL * RT_PYR_NUM && nG >= RT_PYR_MIN && (uint32_t)g0 < 0x800000u) {
+            float *pyr = lds_at(smem, pyr_off);
+            uint32_t *slot = reinterpret_cast<uint32_t *>(pyr) + 24 + (g0 & 7);      // 8 entries of their own, in front of the node masks'
+            const uint32_t key = 0x800000u | (uint32_t)g0;
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)*slot);
+            uint32_t cull;
+            if ((ce >> 8) == key) {
+              cull = ce & 0xFFu;
+            } else {
+              cull = pyramid_cull_tris(P.leaves, pyr, g0);
+              if (lane_now() == 0) *slot = (key << 8) | cull;
+            }
+            w_leaves -= (uint32_t)(nL - nG);
+            if (phase == PH_LEAF && is_cam && child == c0) {
+              if (leaf_test_uniform<SHORT_DIV>(P, ray, g0, 0xFFu & ~cull, hit)) dirty = 0xFFFFFFFFu;
+              phase = PH_POP;
+            }
+            leaf_done = true;
+          }
+        }
+      }
+      if (!leaf_done)
+#endif
 #if RT_LEAF_PAIRS
       {
         const bool in_leaf = phase == PH_LEAF;

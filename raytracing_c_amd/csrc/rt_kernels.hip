@@ -80,7 +80,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
   // tile's camera-ray pyramid
   const int acc_off = (n_lds * RT_LDS_NODE_F4 + __builtin_amdgcn_readfirstlane(wave) * (perm_f4 + 96) + perm_f4) * 16;
   const int pyr_off = (n_lds * RT_LDS_NODE_F4 + __builtin_amdgcn_readfirstlane(wave) * (perm_f4 + 96) + perm_f4 - 16) * 16;
-  // (+ 128 bytes: 32 cache entries, direct mapped by node: (node + 1) << 8 | cull mask)
+  // (the pyramid: planes and origin in floats 0..18, 8 cache entries of leaf masks at 24..31 (0x800000 | group) << 8 | cull mask, then 128
+  //  bytes: 32 cache entries of node masks, direct mapped by node: (node + 1) << 8 | cull mask)
 
 #ifdef RT_LEDGER
   uint32_t *lg = g_ledger + (size_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave) * RT_LEDGER_ROW;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_path_kernel
         for (int q = 0; q < 4; q++) { pyr[q * 4 + 0] = pn[q].x; pyr[q * 4 + 1] = pn[q].y; pyr[q * 4 + 2] = pn[q].z; }
         pyr[16] = o.x; pyr[17] = o.y; pyr[18] = o.z;
       }
-      if (lane < 32) reinterpret_cast<uint32_t *>(pyr)[32 + lane] = 0u;      // the cull masks found for this tile so far
+      if (lane < 40) reinterpret_cast<uint32_t *>(pyr)[24 + lane] = 0u;      // the cull masks found for this tile so far
       bool may_hit = false;
       if (lane < 8) {
         const float *nb = P.nodes + lane;                      // child `lane` of node 0: rows are 8 floats apart
@@ -1168,7 +1169,7 @@ __global__ __launch_bounds__(16 * 64, 1) void rt_test_trace_stream_kernel(RT_KPa
   if (PYRAMID) {
     float *pyr = lds_at(smem, pyr_off);
     if (lane < 19) pyr[lane] = pyr_in[lane];
-    if (lane < 32) reinterpret_cast<uint32_t *>(pyr)[32 + lane] = 0u;
+    if (lane < 40) reinterpret_cast<uint32_t *>(pyr)[24 + lane] = 0u;
   }
   const int leaf_level = P.depth - 1;
   const int n_waves = (int)gridDim.x * 16, wave_id = (int)blockIdx.x * 16 + wave;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void rt_wf_camera_k
         for (int q = 0; q < 4; q++) { pyr[q * 4 + 0] = pn[q].x; pyr[q * 4 + 1] = pn[q].y; pyr[q * 4 + 2] = pn[q].z; }
         pyr[16] = o.x; pyr[17] = o.y; pyr[18] = o.z;
       }
-      if (lane < 32) reinterpret_cast<uint32_t *>(pyr)[32 + lane] = 0u;      // the cull masks found for this tile so far
+      if (lane < 40) reinterpret_cast<uint32_t *>(pyr)[24 + lane] = 0u;      // the cull masks found for this tile so far
       bool may_hit = false;
       if (lane < 8) {
         const float *nb = P.nodes + lane;                      // child `lane` of node 0: rows are 8 floats apart
