@@ -331,7 +331,8 @@ def roofline_block(tot, rays_per_launch, kernel_ms, n_launches, prof, variant_na
                                         "flops_per_executed_lane_instruction": per_lane_inst, "fma_factor": 0.5,
                                         "product": issue * lanes * per_lane_inst * 0.5,
                                         "valu_issue_ceiling_measured": [0.67, 0.70],
-                                        "note": "product = frac (up to the ratio of the nominal 2.4 GHz to itself): every factor is a lever. "
+                                        "note": "product = frac (up to the ratio of the nominal 2.4 GHz to itself): every factor is a lever, and none alone the bound "
+                                                "(DESIGN.md 4.1: 4 % fewer instructions returned 0.6 %). "
                                                 "valu_issue_ceiling_measured = what a straight-line stream of independent v_fma_f32 (plain / mixed "
                                                 "with mul and sub) reaches at 4 waves per SIMD on this chip in the same units "
                                                 "(tools/exp/pk_issue_bench.hip, profiles/r04ad_pk_issue_bench.log: 2.98 / 2.85 cycles per "
