@@ -1140,6 +1140,12 @@ static_assert(RT_PARK_FIELDS * RT_PARK_CAP == RT_PARK_RECORD_DWORDS, "park slice
 #define RT_PYR_MIN 8
 #endif
 #define RT_STEAL_TRIES  16        // failed joins in a row before a wave retires
+#ifndef RT_LEAF_TRIP
+#define RT_LEAF_TRIP 1          // triangles whose scalar loads are in flight together in leaf_test_uniform (2: nine more SGPRs, which spill into the sky loop)
+#endif
+#ifndef RT_LEAF_CULL_MAX
+#define RT_LEAF_CULL_MAX 4     // surviving triangles up to which a camera-ray leaf block takes the culled, triangle-by-triangle form
+#endif
 #ifndef RT_PARK_STOP_PATHS
 #define RT_PARK_STOP_PATHS 0      // hits are shaded at once instead of parked when the tile has at most this many paths left to hand out (0: off)
 #endif
@@ -1318,11 +1324,20 @@ __device__ __forceinline__ bool leaf_test_uniform(const RT_KParams &P, const Ray
   float best = RT_INF, bu = 0.0f, bv = 0.0f;
   int   bi = 0;
   cfloat *lb = as_scalar_ptr(P.leaves) + (size_t)g * 72;
-  // two triangles per trip: their eighteen scalar loads are in flight together (a tile's pyramid leaves two of a group's eight
-  // triangles on average: most blocks are one trip)
+  // RT_LEAF_TRIP 2: two triangles per trip, their eighteen scalar loads in flight together (a tile's pyramid leaves two of a group's
+  // eight triangles on average) -- equal on the helmet, but the nine extra SGPRs cost the sky loop four spill moves per batch (tower
+  // +0.3 %): one per trip is what ships
   while (surv) {
     const int k0 = (int)__builtin_ctz(surv);
     surv &= surv - 1u;
+#if RT_LEAF_TRIP == 1
+    {
+      cfloat *t0 = lb + k0;
+      tri_test_uniform<SHORT_DIV>(r, rt_v3_make(t0[0], t0[24], t0[48]), rt_v3_make(t0[8], t0[32], t0[56]), rt_v3_make(t0[16], t0[40], t0[64]),
+                                  k0, best, bu, bv, bi);
+      continue;
+    }
+#endif
     const bool two = surv != 0u;
     const int k1 = two ? (int)__builtin_ctz(surv) : k0;
     surv &= surv - 1u;                                                     // (0 & anything = 0)
@@ -1413,12 +1428,16 @@ __device__ __forceinline__ void traversal_blocks(const RT_KParams &P, float4 *sm
               cull = pyramid_cull_tris(P.leaves, pyr, g0);
               if (lane_now() == 0) *slot = (key << 8) | cull;
             }
-            w_leaves -= (uint32_t)(nL - nG);
-            if (phase == PH_LEAF && is_cam && child == c0) {
-              if (leaf_test_uniform<SHORT_DIV>(P, ray, g0, 0xFFu & ~cull, hit)) dirty = 0xFFFFFFFFu;
-              phase = PH_POP;
+            // (a group of which the pyramid leaves more than RT_LEAF_CULL_MAX triangles is cheaper in the full block, which has all
+            //  eight in flight at once: tower at 1080p, whose triangles are many tiles wide, +0.8 % without this)
+            if (__popc(0xFFu & ~cull) <= RT_LEAF_CULL_MAX) {
+              w_leaves -= (uint32_t)(nL - nG);
+              if (phase == PH_LEAF && is_cam && child == c0) {
+                if (leaf_test_uniform<SHORT_DIV>(P, ray, g0, 0xFFu & ~cull, hit)) dirty = 0xFFFFFFFFu;
+                phase = PH_POP;
+              }
+              leaf_done = true;
             }
-            leaf_done = true;
           }
         }
       }

@@ -41,8 +41,10 @@ JOBS = [("driver default frame", "helmet", 1024, 1024, 16, 8, 0, 1),
         ("helmet 512^2 x 16", "helmet", 512, 512, 16, 8, 0, 1),
         ("helmet 512^2 x 64", "helmet", 512, 512, 64, 8, 0, 1),
         ("spheres 512^2 x 16", "spheres", 512, 512, 16, 4, 0, 1),
-        ("tower 640x360 x 16", "tower", 640, 360, 16, 12, 0, 1)]
-EXTRA = 5
+        ("tower 640x360 x 16", "tower", 640, 360, 16, 12, 0, 1),
+        ("config #4", "tower", 1920, 1080, 512, 12, 0, 1),
+        ("spheres 1024^2 x 64", "spheres", 1024, 1024, 64, 4, 0, 1)]
+EXTRA = 7
 
 
 def main():
