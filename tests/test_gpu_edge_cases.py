@@ -413,3 +413,41 @@ def test_scene_touch_does_not_absorb_an_edit_nobody_reported(rt, oracle):
     got = rt.render_frame(hs, w, h, s, b, want_accum=True)
     assert np.array_equal(got["accum"], _oracle.render(hs, w, h, s, b)["accum"])
     assert rt.lib.rt_get_frame_timing(C.byref(t)) == 0 and t.upload_ms == 0.0
+
+
+def _picket_fence(n_slivers, depth_jitter, seed):
+    """Thin vertical slivers (a third of a pixel to three pixels wide at 96 x 96) side by side across the view, each at its own depth:
+    every 8 x 8 tile's pyramid cuts through sliver edges, most leaf groups keep a few of their eight triangles per tile."""
+    from raytracing_c_amd.background import procedural_background
+    from raytracing_c_amd.scene import Material, build_scene
+    rng = np.random.default_rng(seed)
+    xs = np.sort(rng.uniform(-1.2, 1.2, n_slivers + 1))
+    tris = []
+    for i in range(n_slivers):
+        z = -3.0 - depth_jitter * rng.uniform(0.0, 1.0)
+        x0, x1 = xs[i], xs[i + 1]
+        y0, y1 = -1.2 + 0.3 * rng.uniform(0, 1), 1.2 - 0.3 * rng.uniform(0, 1)
+        tris.append([[x0, y0, z], [x1, y0, z], [x0, y1, z]])
+        tris.append([[x1, y0, z], [x1, y1, z], [x0, y1, z]])
+    pos = np.asarray(tris, np.float32)
+    nrm = np.tile(np.asarray([0, 0, 1], np.float32), (len(pos), 3, 1))
+    uv = np.zeros((len(pos), 3, 2), np.float32)
+    mats = [Material(base_color=(0.8, 0.7, 0.6), roughness=0.5, metalness=0.2)]
+    return build_scene(pos, nrm, uv, np.zeros((len(pos),), np.int32), mats, [], np.eye(4, dtype=np.float32), 0.9,
+                       procedural_background(64, 32))
+
+
+@pytest.mark.parametrize("n_slivers,depth_jitter,seed", [(40, 0.0, 1), (200, 0.5, 2), (700, 2.0, 3)])
+def test_slivers_across_tile_boundaries(rt, oracle, n_slivers, depth_jitter, seed):
+    """The pyramid-culled LEAF blocks (rt_dev.hip.h pyramid_cull_tris, leaf_test_uniform) drop the triangles a tile's camera rays cannot
+    touch: a frame full of sliver edges on and next to tile boundaries must still be the oracle's sums, image and counters bit for bit."""
+    from tests import _oracle
+    hs = _picket_fence(n_slivers, depth_jitter, seed)
+    w, h, s, b = 96, 96, 64, 3
+    want = _oracle.render(hs, w, h, s, b)
+    got = rt.render_frame(hs, w, h, s, b, want_accum=True)
+    assert np.array_equal(want["accum"], got["accum"])
+    assert np.array_equal(want["image"], got["image"])
+    c = got["counters"]
+    for k in ("rays", "node_visits", "leaf_visits", "shades", "backgrounds"):
+        assert getattr(c, k) == want["counters"][k], k
