@@ -174,6 +174,23 @@ extern int rt_denoise(i32 width, i32 height, void const *d_src, void *d_dst, voi
 extern int rt_render_frame(Scene const *scene, Image const *image, isize samples, isize max_bounces,
                            f32 *linear, u64 *accum);
 
+/* Frames in flight.  A launch of the path kernel ends with 0.6 - 1.0 ms of thinning bounce chains whatever its size
+ * (27 % of the reference driver's default frame, driver.c:733-742); a blocking render_thread_proc() / render() has nothing to
+ * fill that with, a host that has a NEXT frame does: rt_frame_begin() enqueues the frame -- scene check, accumulator clear,
+ * path kernel, resolve, on one of two internal lanes with a stream, buffers and launch state of its own -- and returns a
+ * ticket (>= 0; -1 + rt_last_error() on failure, also when two frames are in flight already); rt_frame_end(ticket) waits
+ * for that frame and fills the pixels of the Image given at begin (the header is copied at begin, the pixels must stay valid
+ * until end).  begin(A), begin(B), end(A), begin(C), end(B) ... keeps two frames on the GPU: the second one's workgroups take
+ * the CUs as the first one's leave them.  Same pixels as render() / rt_render_frame(), bit for bit (per-path seeds, order-free
+ * sums); seed and camera are read at begin; rt_get_counters() / rt_get_frame_timing() after an end describe THAT frame.
+ * The per-frame scene check is the blocking path's: the sampled stamp at begin, the full content check inside rt_frame_end()
+ * while the GPU renders -- a host scene that no longer equals the copy the frame was rendered from is rendered again there,
+ * synchronously.  Do not edit (or rt_scene_touch) a scene between the begin and the end of a frame that renders it.
+ * With rt_set_devices(n > 1) the frame is rendered inside rt_frame_begin() over the n devices (that pipeline has its own
+ * overlap) and rt_frame_end() returns its status. */
+extern int rt_frame_begin(Scene const *scene, Image const *image, isize samples, isize max_bounces);
+extern int rt_frame_end(int ticket);
+
 /* Counters of the last rt_render_accumulate / rt_render_frame on this process
  * (read back synchronously; summed over the devices of a multi-device frame). */
 extern int rt_get_counters(RT_Counters *out);

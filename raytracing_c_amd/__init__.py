@@ -8,4 +8,4 @@ from .native import lib, diag, NativeLibraryMissing, last_error   # noqa: F401
 from .scene import HostScene, build_scene, Material   # noqa: F401
 from .background import procedural_background   # noqa: F401
 from .loaders import load_model, default_camera, camera_from_trs   # noqa: F401
-from .render import render_frame, render_context, Counters   # noqa: F401
+from .render import render_frame, render_context, frame_begin, frame_end, Counters   # noqa: F401

@@ -197,6 +197,9 @@ struct FrameTiming {          // the most recent frame through render_thread_pro
   int   n_devices = 1, slowest_device = 0;
 };
 
+#define RT_FRAME_LANES   2                       // frames in flight behind rt_frame_begin / rt_frame_end
+#define RT_LAUNCH_STATES (1 + RT_FRAME_LANES)
+
 struct Workspace {
   unsigned long long *accum = nullptr;
   size_t              accum_elems = 0;
@@ -225,6 +228,25 @@ struct DevPartition {
   int32_t                *d_owner_slot = nullptr;
 };
 
+// A frame in flight behind rt_frame_begin() / rt_frame_end() (slot 0): its own stream, accumulators and image buffer, and launch
+// state 1 + lane of the device scene it renders from -- two frames overlap on the GPU, the second fills the CUs the first one's
+// thinning bounce chains leave idle (profiles/r05_small_launch.md: a launch ends 0.6 - 1.0 ms after its last unit is handed out).
+struct FrameLane {
+  bool        busy = false;                   // begun, not yet ended
+  bool        finished = false;               // rendered synchronously inside rt_frame_begin (a multi-device frame): nothing to wait for
+  int         rc = 0;
+  hipStream_t stream = nullptr;
+  Workspace   ws;
+  Scene const *scene = nullptr;
+  Image       image;                          // the caller's Image header (the pixels stay the caller's)
+  RT_Render_Params p;
+  RT_Device_Scene *d = nullptr;               // the copy the frame renders from; nullptr once that copy was dropped (free_device_scene waits first)
+  uint64_t    fp = 0;                         // full fingerprint of that copy when the frame began
+  bool        verify = false;
+  FrameTiming timing;
+  double      t_begin = 0.0;
+};
+
 struct Device {
   int        slot = 0, phys = 0;
   bool       ready = false;
@@ -238,6 +260,7 @@ struct Device {
   std::unordered_map<RT_Device_Scene *, Camera>        cameras;
   std::vector<DevPartition>                            parts;   // guarded by g_partition_mutex
   FrameTiming timing;
+  FrameLane  lanes[RT_FRAME_LANES];           // slot 0 only
 };
 
 static Device g_devs[RT_MAX_DEVICES];
@@ -362,6 +385,23 @@ struct FpBlock {            // one block of a host scene's full fingerprint (sce
   uint64_t    h;
 };
 
+// What ONE launch of the path kernel writes besides the accumulators: counters, work head, the tiles' unit counters, parked hits,
+// the schedule feedback.  A device scene owns several (RT_Device_Scene::ls), allocated on first use.
+struct LaunchState {
+  unsigned long long *counters = nullptr;      // RT_N_COUNTERS
+  uint32_t           *work_head = nullptr;
+  uint32_t           *tile_next = nullptr;     // tile-stream kernel: chunks handed out per tile
+  int32_t             tile_next_n = 0;
+  uint32_t           *park = nullptr;          // tile-stream kernel: parked hits, [waves][18][128]
+  int32_t             park_waves = 0;
+  // schedule feedback: rays per 8x8 tile of the previous launch of the same frame shape -> visiting order of the next
+  uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
+  uint32_t    *order = nullptr;
+  int32_t      sched_tiles = 0, sched_cur = 0;
+  bool         sched_valid = false;            // cost[cur^1] holds the costs of a launch with sched_key
+  uint64_t     sched_key = 0;
+};
+
 struct RT_Device_Scene {
   Device      *dev = nullptr;
   float       *nodes = nullptr;
@@ -387,13 +427,9 @@ struct RT_Device_Scene {
   std::unordered_map<uint64_t, int> mat_map;            // (shader.data, kind) -> material id
   std::vector<const Image *>        tex_sources;        // Image of texture k (pool order; the background is one of them)
   std::vector<RT_DTexture>          tex_descs;          // its slot in the texel pool
-  // launch state of this device scene: two device scenes can have launches in flight on two streams at once
-  unsigned long long *counters = nullptr;      // RT_N_COUNTERS
-  uint32_t           *work_head = nullptr;
-  uint32_t           *tile_next = nullptr;     // tile-stream kernel: chunks handed out per tile
-  int32_t             tile_next_n = 0;
-  uint32_t           *park = nullptr;          // tile-stream kernel: parked hits, [waves][18][128]
-  int32_t             park_waves = 0;
+  // launch state: RT_LAUNCH_STATES of them, so that launches of ONE device scene can be in flight on several streams at once
+  // ([0]: the blocking entry points and rt_render_accumulate; [1 + k]: frame lane k of rt_frame_begin / rt_frame_end)
+  LaunchState ls[RT_LAUNCH_STATES];
   // wavefront pipeline (rt_wavefront.hip): record queues between the camera / shade / trace kernels
   uint32_t           *wf_hit0 = nullptr, *wf_hit = nullptr, *wf_ray[2] = {nullptr, nullptr};
   uint32_t           *wf_cnt = nullptr;        // records per chunk: hit0 | hit | ray[0] | ray[1]
@@ -401,27 +437,32 @@ struct RT_Device_Scene {
   uint32_t           *wf_ctl_host = nullptr;   // pinned copy the host reads after a pass
   int64_t             wf_soft0 = 0, wf_hard0 = 0, wf_ray_chunks = 0, wf_hit_chunks = 0;   // capacities in chunks
   int32_t             wf_waves = 0;            // waves the capacities were sized for
-  // schedule feedback: rays per 8x8 tile of the previous launch of the same view -> visiting order of the next
-  uint32_t    *cost[2] = {nullptr, nullptr};   // [cur] is written by the running launch, [cur^1] is last launch's
-  uint32_t    *order = nullptr;
-  int32_t      sched_tiles = 0, sched_cur = 0;
-  bool         sched_valid = false;            // cost[cur^1] holds the costs of a launch with sched_key
-  uint64_t     sched_key = 0;
 };
 
 static void free_device_scene(RT_Device_Scene *d) {      // d->dev->mutex held, d's device current
   if (!d) return;
+  if (d->dev)
+    for (FrameLane &F : d->dev->lanes)        // a frame in flight renders from this copy: let it finish (its pixels are in the lane's buffer)
+      if (F.busy && F.d == d) {
+        if (F.stream) (void)hipStreamSynchronize(F.stream);
+        F.d = nullptr;
+      }
   (void)hipFree(d->nodes);
   (void)hipFree(d->leaves);
   (void)hipFree(d->tris);
   (void)hipFree(d->mats);
   (void)hipFree(d->textures);
   (void)hipFree(d->texels);
-  if (d->dev && d->dev->last_counters == d->counters) d->dev->last_counters = nullptr;
-  (void)hipFree(d->counters);
-  (void)hipFree(d->work_head);
-  (void)hipFree(d->tile_next);
-  (void)hipFree(d->park);
+  for (LaunchState &L : d->ls) {
+    if (d->dev && L.counters && d->dev->last_counters == L.counters) d->dev->last_counters = nullptr;
+    (void)hipFree(L.counters);
+    (void)hipFree(L.work_head);
+    (void)hipFree(L.tile_next);
+    (void)hipFree(L.park);
+    (void)hipFree(L.cost[0]);
+    (void)hipFree(L.cost[1]);
+    (void)hipFree(L.order);
+  }
   (void)hipFree(d->wf_hit0);
   (void)hipFree(d->wf_hit);
   (void)hipFree(d->wf_ray[0]);
@@ -429,9 +470,6 @@ static void free_device_scene(RT_Device_Scene *d) {      // d->dev->mutex held, 
   (void)hipFree(d->wf_cnt);
   (void)hipFree(d->wf_ctl);
   if (d->wf_ctl_host) (void)hipHostFree(d->wf_ctl_host);
-  (void)hipFree(d->cost[0]);
-  (void)hipFree(d->cost[1]);
-  (void)hipFree(d->order);
   delete d;
 }
 
@@ -857,8 +895,8 @@ static RT_Device_Scene *upload_scene_locked(Device &D, Scene const *scene) {
 
   RT_Device_Scene *d = new RT_Device_Scene();
   d->dev = &D;
-  if (hipMalloc((void **)&d->counters, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **)&d->work_head, 64) != hipSuccess) {
+  if (hipMalloc((void **)&d->ls[0].counters, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **)&d->ls[0].work_head, 64) != hipSuccess) {
     rt_fail("rt_scene_upload: out of device memory");
     free_device_scene(d);
     return nullptr;
@@ -1445,8 +1483,8 @@ static int fill_kparams(Device &D, RT_KParams *K, RT_Device_Scene *d, Camera con
   if (n_work > 0x7fffffff) return rt_fail("too many work items (%lld)", (long long)n_work);
   K->n_work = (int32_t)n_work;
   K->accum = (unsigned long long *)d_accum;
-  K->counters = d->counters;
-  K->work_head = d->work_head;
+  K->counters = d->ls[0].counters;      // (render_accumulate_locked puts the launch state it was asked for)
+  K->work_head = d->ls[0].work_head;
   return 0;
 }
 
@@ -1562,14 +1600,20 @@ static int launch_wavefront(Device &D, RT_Device_Scene *d, RT_KParams &K, hipStr
 // Enqueues one launch of the path tracer for p's rank / sample range.  D.mutex held, D's GPU current.
 // ev_prep (optional): recorded between the per-launch preparation and the path kernel.
 static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const *cam, RT_Render_Params const *p, void *d_accum,
-                                    hipStream_t stream, hipEvent_t ev_prep = nullptr) {
+                                    hipStream_t stream, hipEvent_t ev_prep = nullptr, int launch_state = 0) {
   if (ensure_device(D) != 0) return -1;
   if (check_params(p) != 0) return -1;
   if (!d || !d_accum) return rt_fail("rt_render_accumulate: NULL scene or accumulation buffer");
   if (d->dev != &D) return rt_fail("rt_render_accumulate: the scene was uploaded to another device");
   RT_KParams K;
   if (fill_kparams(D, &K, d, cam, p, d_accum) != 0) return -1;
-  D.last_counters = d->counters;
+  if (launch_state < 0 || launch_state >= RT_LAUNCH_STATES) return rt_fail("rt_render_accumulate: launch state %d out of range", launch_state);
+  LaunchState &L = d->ls[launch_state];
+  if (!L.counters) HIP_TRY(hipMalloc((void **)&L.counters, RT_N_COUNTERS * sizeof(unsigned long long)));
+  if (!L.work_head) HIP_TRY(hipMalloc((void **)&L.work_head, 64));
+  K.counters = L.counters;
+  K.work_head = L.work_head;
+  D.last_counters = L.counters;
   // 5 = the tile-stream kernel (the product's only generation); 1-4 exist in the diagnostic build
   int variant = knob_int("RT_KERNEL", 5);
   if (variant < 1 || variant > 5) variant = 5;
@@ -1646,24 +1690,24 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     };
     int32_t ids[6] = {K.width, K.height, K.rank, K.world, K.max_bounces, n_tiles};
     mix(ids, sizeof ids);
-    if (d->sched_tiles != n_tiles) {
-      (void)hipFree(d->cost[0]); (void)hipFree(d->cost[1]); (void)hipFree(d->order);
-      d->cost[0] = d->cost[1] = d->order = nullptr;
-      d->sched_tiles = 0;
-      d->sched_valid = false;
-      HIP_TRY(hipMalloc(&d->cost[0], (size_t)n_tiles * 4));
-      HIP_TRY(hipMalloc(&d->cost[1], (size_t)n_tiles * 4));
-      HIP_TRY(hipMalloc(&d->order, (size_t)n_tiles * 4));
-      d->sched_tiles = n_tiles;
+    if (L.sched_tiles != n_tiles) {
+      (void)hipFree(L.cost[0]); (void)hipFree(L.cost[1]); (void)hipFree(L.order);
+      L.cost[0] = L.cost[1] = L.order = nullptr;
+      L.sched_tiles = 0;
+      L.sched_valid = false;
+      HIP_TRY(hipMalloc(&L.cost[0], (size_t)n_tiles * 4));
+      HIP_TRY(hipMalloc(&L.cost[1], (size_t)n_tiles * 4));
+      HIP_TRY(hipMalloc(&L.order, (size_t)n_tiles * 4));
+      L.sched_tiles = n_tiles;
     }
-    if (d->sched_valid && d->sched_key == key) {
-      cost_prev = d->cost[d->sched_cur ^ 1];
-      K.order = d->order;
+    if (L.sched_valid && L.sched_key == key) {
+      cost_prev = L.cost[L.sched_cur ^ 1];
+      K.order = L.order;
     }
-    K.tile_cost = d->cost[d->sched_cur];
-    d->sched_cur ^= 1;                // after this launch, cost[sched_cur ^ 1] is the buffer just written
-    d->sched_key = key;
-    d->sched_valid = true;
+    K.tile_cost = L.cost[L.sched_cur];
+    L.sched_cur ^= 1;                // after this launch, cost[sched_cur ^ 1] is the buffer just written
+    L.sched_key = key;
+    L.sched_valid = true;
   }
 
   if (variant == 5) {
@@ -1679,16 +1723,16 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     K.n_chunks_tile = 32 * K.n_sample_blocks;          // units: 8 rows x sample blocks x 4 pixel pairs
     K.drain_thresh = knob_int("RT_DRAIN_THRESH", K.sched_thresh);
     if (K.drain_thresh < 1 || K.drain_thresh > 64) K.drain_thresh = K.sched_thresh;
-    if (d->tile_next_n < K.n_tiles) {
-      (void)hipFree(d->tile_next);
-      d->tile_next = nullptr;
-      d->tile_next_n = 0;
+    if (L.tile_next_n < K.n_tiles) {
+      (void)hipFree(L.tile_next);
+      L.tile_next = nullptr;
+      L.tile_next_n = 0;
       // [n_tiles] chunk counters, then [ceil(n_tiles / 64)] open-tile counts of the groups
-      HIP_TRY(hipMalloc(&d->tile_next, ((size_t)K.n_tiles + (size_t)((K.n_tiles + 63) / 64)) * 4));
-      d->tile_next_n = K.n_tiles;
+      HIP_TRY(hipMalloc(&L.tile_next, ((size_t)K.n_tiles + (size_t)((K.n_tiles + 63) / 64)) * 4));
+      L.tile_next_n = K.n_tiles;
     }
-    K.tile_next = d->tile_next;
-    K.open_groups = d->tile_next + d->tile_next_n;
+    K.tile_next = L.tile_next;
+    K.open_groups = L.tile_next + L.tile_next_n;
     int64_t chunks = (int64_t)K.n_tiles * K.n_chunks_tile;
     n_waves = D.num_cus * waves_per_cu;
     if ((int64_t)n_waves > chunks) n_waves = (int)chunks;
@@ -1717,22 +1761,22 @@ static int render_accumulate_locked(Device &D, RT_Device_Scene *d, Camera const 
     K.park = nullptr;
     if (!wavefront && knob_int("RT_PARK", 1) != 0 && K.max_bounces < (1 << 26)) {      // (a parked record keeps the bounce count in 26 bits)
       const int grid_waves = (n_waves + wg_waves - 1) / wg_waves * wg_waves;         // whole workgroups are launched
-      if (d->park_waves < grid_waves) {
-        (void)hipFree(d->park);
-        d->park = nullptr;
-        d->park_waves = 0;
+      if (L.park_waves < grid_waves) {
+        (void)hipFree(L.park);
+        L.park = nullptr;
+        L.park_waves = 0;
         const size_t slice_bytes = (size_t)RT_PARK_RECORD_DWORDS * 4;      // a wave's slice: 18 fields x 128 records (rt_device.h)
-        HIP_TRY(hipMalloc(&d->park, (size_t)grid_waves * slice_bytes));
-        d->park_waves = grid_waves;
+        HIP_TRY(hipMalloc(&L.park, (size_t)grid_waves * slice_bytes));
+        L.park_waves = grid_waves;
       }
-      K.park = d->park;
+      K.park = L.park;
     }
   }
 
   // ---- ONE preparation launch: counters, work head, tile / unit counters, this launch's cost buffer, tile order ----
   {
-    int rc2 = rt_launch_prepare(K.n_tiles, variant == 5 ? K.tile_next : nullptr, variant == 5 ? K.open_groups : nullptr, d->counters,
-                                d->work_head, K.tile_cost, cost_prev, cost_prev ? d->order : nullptr, stream);
+    int rc2 = rt_launch_prepare(K.n_tiles, variant == 5 ? K.tile_next : nullptr, variant == 5 ? K.open_groups : nullptr, L.counters,
+                                L.work_head, K.tile_cost, cost_prev, cost_prev ? L.order : nullptr, stream);
     if (rc2 != 0) return rt_fail("prepare kernel launch failed: %s", hipGetErrorString((hipError_t)rc2));
   }
   if (ev_prep) HIP_TRY(hipEventRecord(ev_prep, stream));
@@ -1840,8 +1884,7 @@ extern "C" int rt_untile(i32 width, i32 height, i32 world, void const *d_all_til
   return untile_on(D, width, height, world, d_all_tiles, d_image, (hipStream_t)stream);
 }
 
-static int ensure_frame_buffers(Device &D, int width, int height, size_t tiles_bytes, size_t all_tiles_bytes) {
-  Workspace &W = D.ws;
+static int ensure_ws_buffers(Workspace &W, int width, int height, size_t tiles_bytes, size_t all_tiles_bytes) {
   size_t pixels = (size_t)width * height;
   if (W.accum_elems < pixels * 3) {
     (void)hipFree(W.accum);
@@ -1877,6 +1920,10 @@ static int ensure_frame_buffers(Device &D, int width, int height, size_t tiles_b
   for (int i = 0; i < 5; i++)
     if (!W.ev_frame[i]) HIP_TRY(hipEventCreate(&W.ev_frame[i]));
   return 0;
+}
+
+static int ensure_frame_buffers(Device &D, int width, int height, size_t tiles_bytes, size_t all_tiles_bytes) {
+  return ensure_ws_buffers(D.ws, width, height, tiles_bytes, all_tiles_bytes);
 }
 
 static int copy_image_out(Image const *image, const uint8_t *d_image, int width, int height, hipStream_t stream) {
@@ -2010,7 +2057,7 @@ static void enqueue_device_frame(MultiFrame &J, int r) {
   if (same_gpu) e = hipMemcpyAsync(dst, W.tiles, J.tiles_bytes, hipMemcpyDeviceToDevice, stream);
   else if (direct) e = hipMemcpyPeerAsync(dst, D0.phys, W.tiles, D.phys, J.tiles_bytes, stream);      // one xGMI link per device
   else { e = hipMemcpyAsync(W.tiles_host, W.tiles, J.tiles_bytes, hipMemcpyDeviceToHost, stream); J.staged[r] = true; }
-  if (e == hipSuccess) e = hipMemcpyAsync(W.counters_host, d->counters, RT_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(W.counters_host, d->ls[0].counters, RT_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipEventRecord(W.ev_frame[4], stream);
   if (e != hipSuccess) { device_fail(J, r, hipGetErrorString(e)); return; }
   J.enqueue_ms[r] = (float)(now_ms() - t_enq);
@@ -2237,6 +2284,109 @@ extern "C" int rt_render_frame(Scene const *scene, Image const *image, isize sam
   Device &D = dev0();
   std::lock_guard<std::mutex> lock(D.mutex);
   return render_frame_locked(scene, image, samples, max_bounces, linear, accum);
+}
+
+// ---- frames in flight (rt_hip.h) ---------------------------------------------------------------------------------------------
+extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samples, isize max_bounces) {
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  const double t_start = now_ms();
+  if (ensure_device(D) != 0) return -1;
+  if (!scene || !image) return rt_fail("rt_frame_begin: NULL scene or image");
+  if (image->pixels.data && image->components < 3) return rt_fail("rt_frame_begin: image needs >= 3 components");
+  if (image->pixels.data && image->stride < image->width) return rt_fail("rt_frame_begin: image stride < width");
+  RT_Render_Params p;
+  memset(&p, 0, sizeof p);
+  p.width = (i32)image->width;
+  p.height = (i32)image->height;
+  p.samples = (i32)samples;
+  p.max_bounces = (i32)max_bounces;
+  p.seed = g_seed.load();
+  p.rank = 0;
+  p.world = 1;
+  if (check_params(&p) != 0) return -1;
+  int ticket = -1;
+  for (int k = 0; k < RT_FRAME_LANES; k++)
+    if (!D.lanes[k].busy) { ticket = k; break; }
+  if (ticket < 0) return rt_fail("rt_frame_begin: %d frames are in flight already (rt_frame_end one of them first)", RT_FRAME_LANES);
+  FrameLane &F = D.lanes[ticket];
+  F.scene = scene; F.image = *image; F.p = p; F.d = nullptr; F.fp = 0; F.rc = 0; F.finished = false; F.timing = FrameTiming();
+  F.t_begin = t_start;
+  if (rt_device_count() > 1) {
+    // a frame over N devices has its own pipeline (render_frame_multi): rendered here and now, rt_frame_end() reports how it went
+    F.rc = render_frame_locked(scene, image, samples, max_bounces, nullptr, nullptr);
+    F.finished = true;
+    F.busy = true;
+    return ticket;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_multi_mutex);
+    g_multi_counters_valid = false;
+  }
+  if (!F.stream) HIP_TRY(hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
+  if (ensure_ws_buffers(F.ws, p.width, p.height, 0, 0) != 0) return -1;
+  Workspace &W = F.ws;
+  const size_t pixels = (size_t)p.width * p.height;
+  RT_Device_Scene *d = cached_scene_locked(D, scene, &F.timing.stamp_ms, &F.timing.upload_ms);
+  if (!d) return -1;
+  const double t_enq = now_ms();
+  HIP_TRY(hipEventRecord(W.ev_frame[0], F.stream));
+  HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 3 * sizeof(unsigned long long), F.stream));
+  if (render_accumulate_locked(D, d, &scene->camera, &p, W.accum, F.stream, W.ev_frame[1], 1 + ticket) != 0) return -1;
+  HIP_TRY(hipEventRecord(W.ev_frame[2], F.stream));
+  if (resolve_on(D, &p, W.accum, nullptr, W.image, nullptr, F.stream) != 0) return -1;
+  HIP_TRY(hipEventRecord(W.ev_frame[3], F.stream));
+  F.timing.enqueue_ms = (float)(now_ms() - t_enq);
+  F.d = d;
+  F.fp = d->full_fp;
+  F.verify = !scene_is_static(scene) && F.timing.upload_ms == 0.0f;      // (a copy made for this frame IS the host scene)
+  F.busy = true;
+  return ticket;
+}
+
+extern "C" int rt_frame_end(int ticket) {
+  Device &D = dev0();
+  std::lock_guard<std::mutex> lock(D.mutex);
+  if (ticket < 0 || ticket >= RT_FRAME_LANES || !D.lanes[ticket].busy) return rt_fail("rt_frame_end: no frame in flight with ticket %d", ticket);
+  FrameLane &F = D.lanes[ticket];
+  if (F.finished) { F.busy = false; return F.rc; }
+  if (ensure_device(D) != 0) { F.busy = false; return -1; }
+  Workspace &W = F.ws;
+  // the full content check of the blocking path (render_frame_locked), on this thread, while the GPU renders: the frame came from
+  // a copy with fingerprint F.fp; a host scene that no longer has it is rendered again, like there
+  if (F.verify) {
+    const double t_v = now_ms();
+    const uint64_t now = scene_fingerprint(F.scene);
+    F.timing.verify_ms = (float)(now_ms() - t_v);
+    if (now != F.fp) {
+      (void)hipStreamSynchronize(F.stream);
+      auto it = D.scene_cache.find(F.scene);
+      if (it != D.scene_cache.end() && it->second->full_fp != now) {
+        free_device_scene(it->second);        // (waits for the other lane if that renders from it)
+        D.scene_cache.erase(it);
+      }
+      F.busy = false;
+      F.d = nullptr;
+      return render_frame_locked(F.scene, &F.image, F.p.samples, F.p.max_bounces, nullptr, nullptr);
+    }
+  }
+  hipError_t e = hipStreamSynchronize(F.stream);
+  F.busy = false;
+  if (e != hipSuccess) return rt_fail("rt_frame_end: %s", hipGetErrorString(e));
+  if (copy_image_out(&F.image, W.image, F.p.width, F.p.height, F.stream) != 0) return -1;
+  HIP_TRY(hipEventRecord(W.ev_frame[4], F.stream));
+  HIP_TRY(hipStreamSynchronize(F.stream));
+  HIP_TRY(hipGetLastError());
+  D.last_counters = F.d ? F.d->ls[1 + ticket].counters : nullptr;       // rt_get_counters() = this frame's
+  F.d = nullptr;
+  FrameTiming T = F.timing;
+  T.gpu_prep_ms = event_ms(W.ev_frame[0], W.ev_frame[1]);
+  T.gpu_path_ms = event_ms(W.ev_frame[1], W.ev_frame[2]);
+  T.gpu_resolve_ms = event_ms(W.ev_frame[2], W.ev_frame[3]);
+  T.gpu_copy_ms = event_ms(W.ev_frame[3], W.ev_frame[4]);
+  T.total_ms = (float)(now_ms() - F.t_begin);
+  D.timing = T;
+  return 0;
 }
 
 // Where the time of the last frame behind render_thread_proc / render / rt_render_frame went (one-device frames; a

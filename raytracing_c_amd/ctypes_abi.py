@@ -158,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_verify", "rt_scene_touch", "rt_scene_set_static", "rt_get_frame_timing",
     "rt_scene_upload", "rt_scene_release", "rt_scene_invalidate", "rt_scene_device_bytes", "rt_set_camera",
     "rt_chunk_count", "rt_chunk_owner", "rt_local_chunk_count", "rt_max_local_chunk_count", "rt_local_chunk_list", "rt_render_accumulate", "rt_resolve", "rt_untile",
-    "rt_denoise", "rt_render_frame", "rt_get_counters", "rt_get_skipped_root_visits", "rt_last_kernel_ms", "rt_kernel_timing_reset", "rt_kernel_timing_mean_ms",
+    "rt_denoise", "rt_render_frame", "rt_frame_begin", "rt_frame_end", "rt_get_counters", "rt_get_skipped_root_visits", "rt_last_kernel_ms", "rt_kernel_timing_reset", "rt_kernel_timing_mean_ms",
 ]
 
 # include/rt_hip_diag.h: exported by librt_hip_diag.so only (which also exports everything above); the product library must

@@ -123,6 +123,9 @@ def _declare(d):
     d.rt_resolve.argtypes = [P(abi.RT_Render_Params), vp, vp, vp, vp, vp]
     d.rt_untile.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     d.rt_render_frame.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize, vp, vp]
+    if hasattr(d, "rt_frame_begin"):                       # (absent from older builds loaded as A/B partners)
+        d.rt_frame_begin.argtypes = [P(abi.Scene), P(abi.Image), abi.isize, abi.isize]
+        d.rt_frame_end.argtypes = [C.c_int]
     d.rt_get_counters.argtypes = [P(abi.RT_Counters)]
     if hasattr(d, "rt_get_skipped_root_visits"):           # (absent from older builds that tools/exp_small_ab.sh loads as A/B partners)
         d.rt_get_skipped_root_visits.argtypes = [P(C.c_uint64)]

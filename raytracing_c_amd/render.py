@@ -60,6 +60,27 @@ def render_frame(hs: HostScene, width, height, samples, max_bounces, seed=0x1234
     return dict(image=out, linear=linear, accum=accum, counters=get_counters(lib))
 
 
+def frame_begin(hs: HostScene, width, height, samples, max_bounces, seed=0x1234ABCD, lib=None):
+    """rt_frame_begin (rt_hip.h): enqueue a frame, return (ticket, pixel array the frame will land in, keep-alive)."""
+    lib = lib or _lib
+    lib.rt_set_seed(seed)
+    out = np.zeros((height, width, 3), np.uint8)
+    img, keep = make_image(out)
+    img.pixels.data = out.ctypes.data
+    ticket = lib.rt_frame_begin(C.byref(hs.scene), C.byref(img), samples, max_bounces)
+    if ticket < 0:
+        raise RuntimeError("rt_frame_begin failed: " + last_error(lib))
+    return ticket, out, (img, keep)
+
+
+def frame_end(ticket, lib=None):
+    """rt_frame_end: wait for the frame of `ticket`; its pixels are in the array frame_begin returned.  Returns its counters."""
+    lib = lib or _lib
+    if lib.rt_frame_end(ticket) != 0:
+        raise RuntimeError("rt_frame_end failed: " + last_error(lib))
+    return get_counters(lib)
+
+
 def render_context(hs: HostScene, width, height, samples, max_bounces, n_threads=1, seed=0x1234ABCD, lib=None, fill=0):
     """The reference driver's protocol (driver.c:793-818): n_threads threads enter
     render_thread_proc on one Rendering_Context, the caller polls is_finished."""

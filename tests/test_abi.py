@@ -95,6 +95,11 @@ def test_render_fails_loudly_without_gpu():
     assert rc != 0
     assert "no HIP device" in rt.last_error() or "failed" in rt.last_error()
     assert (img == 7).all(), "image must stay untouched"
+    rt.lib.rt_clear_error()
+    assert rt.lib.rt_frame_begin(C.byref(hs.scene), C.byref(image), 4, 2) < 0        # frames in flight: no device, no ticket
+    assert "no HIP device" in rt.last_error() or "failed" in rt.last_error()
+    assert rt.lib.rt_frame_end(0) != 0 and "no frame in flight" in rt.last_error()
+    assert (img == 7).all()
     # the reference protocol still completes (n_threads reaches 0) so a driver does not hang
     r = rt.render_context(hs, 16, 16, 2, 2, n_threads=2)
     assert r["finished"] and r["n_threads"] == 0
