@@ -406,6 +406,38 @@ def boundary_cost(rt, abi, hs, frames=8):
     out = {"frame": f"{w}x{h}, {s} spp, {b} bounces (driver.c:733-742), via render_thread_proc", "frames": frames}
     out.update({n: v for n, v in zip(names, med)})
     out["non_kernel_share"] = (out["total_ms"] - out["gpu_path_ms"]) / out["total_ms"] if out["total_ms"] > 0 else None
+    # the same frames for a host that has a NEXT frame: rt_frame_begin / rt_frame_end keep two on the GPU (the second one's
+    # workgroups take the CUs the first one's thinning bounce chains leave); host wall per frame against the blocking rt_render_frame
+    if hasattr(rt.lib, "rt_frame_begin"):
+        import numpy as np
+        img = np.zeros((h, w, 3), np.uint8)
+        image, _keep = rt.scene.make_image(img)
+        image.pixels.data = img.ctypes.data
+        n = 4 * frames
+
+        def run(pipelined):
+            t0 = time.perf_counter()
+            pending = []
+            for _ in range(n):
+                if pipelined:
+                    if len(pending) == 2 and rt.lib.rt_frame_end(pending.pop(0)) != 0:
+                        return None
+                    pending.append(rt.lib.rt_frame_begin(C.byref(hs.scene), C.byref(image), s, b))
+                    if pending[-1] < 0:
+                        return None
+                elif rt.lib.rt_render_frame(C.byref(hs.scene), C.byref(image), s, b, None, None) != 0:
+                    return None
+            for t in pending:
+                if rt.lib.rt_frame_end(t) != 0:
+                    return None
+            return (time.perf_counter() - t0) * 1e3 / n
+        run(True)
+        blocking_ms, pipelined_ms = run(False), run(True)
+        if blocking_ms is None or pipelined_ms is None:
+            return {"error": rt.last_error()}
+        out["frames_in_flight"] = {"blocking_ms_per_frame": blocking_ms, "two_in_flight_ms_per_frame": pipelined_ms, "frames": n,
+                                   "note": "host wall per frame incl. the copy to the host; rt_frame_begin / rt_frame_end (rt_hip.h), "
+                                           "same pixels as the blocking call (tests/test_gpu_frames_in_flight.py)"}
     return out
 
 
@@ -547,7 +579,11 @@ def main():
         if not second:
             raise RuntimeError("rt_scene_upload: " + rt.last_error())
         dscenes.append(second)
-        render_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        # two streams on ONE hardware queue run their kernels one after the other, and the runtime multiplexes a process's
+        # streams onto GPU_MAX_HW_QUEUES (4) queues per priority: the two render streams take different priorities, so they
+        # never share one whatever else (copy / exchange / RCCL streams) the process creates (profiles/r05_frames_in_flight.md)
+        prio = [0, -1] if os.environ.get("RT_BENCH_STREAM_PRIO", "1") != "0" else [0, 0]
+        render_streams = [torch.cuda.Stream(device=dev, priority=prio[0]), torch.cuda.Stream(device=dev, priority=prio[1])]
     ev_rendered = [torch.cuda.Event() for _ in range(2)]
     ev_posted = [torch.cuda.Event() for _ in range(2)]
 

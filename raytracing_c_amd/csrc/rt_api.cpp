@@ -197,7 +197,9 @@ struct FrameTiming {          // the most recent frame through render_thread_pro
   int   n_devices = 1, slowest_device = 0;
 };
 
+#ifndef RT_FRAME_LANES
 #define RT_FRAME_LANES   2                       // frames in flight behind rt_frame_begin / rt_frame_end
+#endif
 #define RT_LAUNCH_STATES (1 + RT_FRAME_LANES)
 
 struct Workspace {
@@ -2286,6 +2288,18 @@ extern "C" int rt_render_frame(Scene const *scene, Image const *image, isize sam
   return render_frame_locked(scene, image, samples, max_bounces, linear, accum);
 }
 
+// A lane's stream must not share a HARDWARE queue with the other lane's: the runtime multiplexes its streams onto a few HSA queues
+// (GPU_MAX_HW_QUEUES, 4 by default), and two streams on one queue run their kernels one after the other -- measured: with ONE more
+// stream in the process (a torch side stream) two plain non-blocking streams landed on one queue and the overlap was gone (2.67
+// instead of 2.23 ms per default frame, gpurun_out/r05fl).  The runtime pools its queues per stream priority, so the lanes take
+// different priorities: never the same queue, whatever else the process creates.  (A stream with an all-ones CU mask owns its queue
+// too and measures the same, but it is a blocking stream: it would wait for every null-stream operation of the host.)
+static hipError_t create_lane_stream(hipStream_t *s, int lane) {
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, lane == 0 ? 0 : hi);
+}
+
 // ---- frames in flight (rt_hip.h) ---------------------------------------------------------------------------------------------
 extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samples, isize max_bounces) {
   Device &D = dev0();
@@ -2323,7 +2337,7 @@ extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samp
     std::lock_guard<std::mutex> lk(g_multi_mutex);
     g_multi_counters_valid = false;
   }
-  if (!F.stream) HIP_TRY(hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
+  if (!F.stream) HIP_TRY(create_lane_stream(&F.stream, ticket));
   if (ensure_ws_buffers(F.ws, p.width, p.height, 0, 0) != 0) return -1;
   Workspace &W = F.ws;
   const size_t pixels = (size_t)p.width * p.height;

@@ -20,6 +20,15 @@ from raytracing_c_amd.scene import make_image           # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+depth = int(os.environ.get("EXP_DEPTH", "2"))            # frames in flight (a library built with -DRT_FRAME_LANES=3 takes 3)
+if os.environ.get("EXP_TORCH"):                        # a process that also runs torch streams (bench.py): do the lanes still overlap?
+    import torch
+    _keep_streams = [torch.cuda.Stream() for _ in range(int(os.environ["EXP_TORCH"]))]
+    _x = torch.zeros(1 << 20, device="cuda")
+    for st in _keep_streams:
+        with torch.cuda.stream(st):
+            _x += 1
+    torch.cuda.synchronize()
 assert rt.lib.rt_init(0) == 0, rt.last_error()
 
 JOBS = [("driver default frame (driver.c:733-742) on the helmet", "helmet", 1024, 1024, 16, 8),
@@ -33,7 +42,7 @@ JOBS = [("driver default frame (driver.c:733-742) on the helmet", "helmet", 1024
 def blocking(hs, imgs, n, s, b):
     t0 = time.perf_counter()
     for f in range(n):
-        img = imgs[f & 1][1]
+        img = imgs[f % len(imgs)][1]
         assert rt.lib.rt_render_frame(C.byref(hs.scene), C.byref(img), s, b, None, None) == 0, rt.last_error()
     return (time.perf_counter() - t0) * 1e3 / n
 
@@ -42,9 +51,9 @@ def pipelined(hs, imgs, n, s, b):
     t0 = time.perf_counter()
     pending = []
     for f in range(n):
-        if len(pending) == 2:
+        if len(pending) == depth:
             assert rt.lib.rt_frame_end(pending.pop(0)) == 0, rt.last_error()
-        t = rt.lib.rt_frame_begin(C.byref(hs.scene), C.byref(imgs[f & 1][1]), s, b)
+        t = rt.lib.rt_frame_begin(C.byref(hs.scene), C.byref(imgs[f % len(imgs)][1]), s, b)
         assert t >= 0, rt.last_error()
         pending.append(t)
     while pending:
@@ -54,11 +63,11 @@ def pipelined(hs, imgs, n, s, b):
 
 print("| frame | blocking, ms per frame | two frames in flight | | blocking, static scene | two in flight, static scene | |")
 print("|---|---|---|---|---|---|---|")
-for label, cfg, w, h, s, b in JOBS:
+for label, cfg, w, h, s, b in JOBS[:int(os.environ.get("EXP_JOBS", "99"))]:
     hs, _ = load_config(cfg)
     n = frames if w * h * s < 2e8 else max(6, frames // 5)
     imgs = []
-    for k in range(2):
+    for k in range(4):
         out = np.zeros((h, w, 3), np.uint8)
         img, keep = make_image(out)
         img.pixels.data = out.ctypes.data
@@ -69,7 +78,7 @@ for label, cfg, w, h, s, b in JOBS:
         blocking(hs, imgs, 4, s, b)
         ref = imgs[1][0].copy()
         pipelined(hs, imgs, 4, s, b)
-        assert np.array_equal(ref, imgs[1][0]) and np.array_equal(ref, imgs[0][0]), "pipelined frame differs from the blocking one"
+        assert all(np.array_equal(ref, im[0]) for im in imgs), "pipelined frame differs from the blocking one"
         bl, pl = [], []
         for r in range(reps):
             bl.append(blocking(hs, imgs, n, s, b))
