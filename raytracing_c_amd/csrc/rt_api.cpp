@@ -242,6 +242,7 @@ struct FrameLane {
   Scene const *scene = nullptr;
   Image       image;                          // the caller's Image header (the pixels stay the caller's)
   RT_Render_Params p;
+  Camera      camera;                         // scene->camera when the frame began
   RT_Device_Scene *d = nullptr;               // the copy the frame renders from; nullptr once that copy was dropped (free_device_scene waits first)
   uint64_t    fp = 0;                         // full fingerprint of that copy when the frame began
   bool        verify = false;
@@ -2209,7 +2210,7 @@ static int render_frame_multi(Scene const *scene, Image const *image, RT_Render_
 }
 
 static int render_frame_locked(Scene const *scene, Image const *image, isize samples, isize max_bounces,
-                               f32 *linear, u64 *accum) {
+                               f32 *linear, u64 *accum, Camera const *camera = nullptr, u32 const *seed = nullptr) {
   Device &D = dev0();
   const double t_start = now_ms();
   if (ensure_device(D) != 0) return -1;
@@ -2222,7 +2223,7 @@ static int render_frame_locked(Scene const *scene, Image const *image, isize sam
   p.height = (i32)image->height;
   p.samples = (i32)samples;
   p.max_bounces = (i32)max_bounces;
-  p.seed = g_seed.load();
+  p.seed = seed ? *seed : g_seed.load();      // (camera / seed given: a frame of rt_frame_begin rendered again, as it was begun)
   p.rank = 0;
   p.world = 1;
   if (check_params(&p) != 0) return -1;
@@ -2249,7 +2250,7 @@ static int render_frame_locked(Scene const *scene, Image const *image, isize sam
     const double t_enq = now_ms();
     HIP_TRY(hipEventRecord(W.ev_frame[0], stream));
     HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 3 * sizeof(unsigned long long), stream));
-    if (render_accumulate_locked(D, d, &scene->camera, &p, W.accum, stream, W.ev_frame[1]) != 0) return -1;
+    if (render_accumulate_locked(D, d, camera ? camera : &scene->camera, &p, W.accum, stream, W.ev_frame[1]) != 0) return -1;
     HIP_TRY(hipEventRecord(W.ev_frame[2], stream));
     if (resolve_on(D, &p, W.accum, nullptr, W.image, linear ? W.linear : nullptr, stream) != 0) return -1;
     HIP_TRY(hipEventRecord(W.ev_frame[3], stream));
@@ -2324,7 +2325,7 @@ extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samp
     if (!D.lanes[k].busy) { ticket = k; break; }
   if (ticket < 0) return rt_fail("rt_frame_begin: %d frames are in flight already (rt_frame_end one of them first)", RT_FRAME_LANES);
   FrameLane &F = D.lanes[ticket];
-  F.scene = scene; F.image = *image; F.p = p; F.d = nullptr; F.fp = 0; F.rc = 0; F.finished = false; F.timing = FrameTiming();
+  F.scene = scene; F.image = *image; F.p = p; F.camera = scene->camera; F.d = nullptr; F.fp = 0; F.rc = 0; F.finished = false; F.timing = FrameTiming();
   F.t_begin = t_start;
   if (rt_device_count() > 1) {
     // a frame over N devices has its own pipeline (render_frame_multi): rendered here and now, rt_frame_end() reports how it went
@@ -2346,7 +2347,7 @@ extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samp
   const double t_enq = now_ms();
   HIP_TRY(hipEventRecord(W.ev_frame[0], F.stream));
   HIP_TRY(hipMemsetAsync(W.accum, 0, pixels * 3 * sizeof(unsigned long long), F.stream));
-  if (render_accumulate_locked(D, d, &scene->camera, &p, W.accum, F.stream, W.ev_frame[1], 1 + ticket) != 0) return -1;
+  if (render_accumulate_locked(D, d, &F.camera, &p, W.accum, F.stream, W.ev_frame[1], 1 + ticket) != 0) return -1;
   HIP_TRY(hipEventRecord(W.ev_frame[2], F.stream));
   if (resolve_on(D, &p, W.accum, nullptr, W.image, nullptr, F.stream) != 0) return -1;
   HIP_TRY(hipEventRecord(W.ev_frame[3], F.stream));
@@ -2381,7 +2382,7 @@ extern "C" int rt_frame_end(int ticket) {
       }
       F.busy = false;
       F.d = nullptr;
-      return render_frame_locked(F.scene, &F.image, F.p.samples, F.p.max_bounces, nullptr, nullptr);
+      return render_frame_locked(F.scene, &F.image, F.p.samples, F.p.max_bounces, nullptr, nullptr, &F.camera, &F.p.seed);
     }
   }
   hipError_t e = hipStreamSynchronize(F.stream);

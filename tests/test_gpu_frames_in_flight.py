@@ -100,21 +100,29 @@ def test_in_place_edit_before_end_is_rendered_again(rt, oracle):
     i = int(T.len) // 2 + 37
     x0 = T.x[0][i]
     T.x[0][i] = x0 + 0.25
+    fov0 = float(hs.scene.camera.fov)
     try:
         want = _oracle.render(hs, w, h, s, b)
+        want2 = _oracle.render(hs, w, h, s, b, seed=22)
         t1, out1, k1 = rt.frame_begin(hs, w, h, s, b)            # both lanes render from the stale copy
-        t2, out2, k2 = rt.frame_begin(hs, w, h, s, b)
+        t2, out2, k2 = rt.frame_begin(hs, w, h, s, b, seed=22)
+        # seed and camera belong to the frame as it was BEGUN: what the host sets up for its next frame does not leak into a
+        # frame that rt_frame_end() has to render again
+        rt.lib.rt_set_seed(999)
+        hs.scene.camera.fov = fov0 * 0.5
         rt.frame_end(t1)
         tm = abi.RT_Frame_Timing()
         assert rt.lib.rt_get_frame_timing(C.byref(tm)) == 0 and tm.upload_ms > 0.0
         rt.frame_end(t2)
-        assert np.array_equal(out1, want["image"]) and np.array_equal(out2, want["image"])
+        hs.scene.camera.fov = fov0
+        assert np.array_equal(out1, want["image"]) and np.array_equal(out2, want2["image"])
         t3, out3, k3 = rt.frame_begin(hs, w, h, s, b)            # unchanged now: the fresh copy serves
         rt.frame_end(t3)
         assert rt.lib.rt_get_frame_timing(C.byref(tm)) == 0 and tm.upload_ms == 0.0 and tm.verify_ms > 0.0
         assert np.array_equal(out3, want["image"])
     finally:
         T.x[0][i] = x0
+        hs.scene.camera.fov = fov0
         rt.lib.rt_scene_invalidate(C.byref(hs.scene))
 
 

@@ -63,6 +63,8 @@ def pipelined(hs, imgs, n, s, b):
 
 print("| frame | blocking, ms per frame | two frames in flight | | blocking, static scene | two in flight, static scene | |")
 print("|---|---|---|---|---|---|---|")
+if os.environ.get("EXP_ONLY"):
+    JOBS = [JOBS[int(k)] for k in os.environ["EXP_ONLY"].split(",")]
 for label, cfg, w, h, s, b in JOBS[:int(os.environ.get("EXP_JOBS", "99"))]:
     hs, _ = load_config(cfg)
     n = frames if w * h * s < 2e8 else max(6, frames // 5)
