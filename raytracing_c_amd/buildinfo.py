@@ -13,7 +13,9 @@ KERNEL_SOURCES = ("csrc/rt_kernels.hip", "csrc/rt_dev.hip.h", "csrc/rt_device.h"
 def hipflags():
     txt = open(os.path.join(_HERE, "csrc", "Makefile")).read()
     m = re.search(r"^HIPFLAGS\s*:=\s*(.*)$", txt, re.M)
-    return m.group(1).strip() if m else ""
+    flags = m.group(1).strip() if m else ""
+    r = re.search(r"^RAFLAGS\s*:=\s*(.*)$", txt, re.M)           # (the register-allocation flags HIPFLAGS includes by name)
+    return flags.replace("$(RAFLAGS)", r.group(1).strip() if r else "")
 
 
 def kernel_source_hash():

@@ -4,7 +4,7 @@
 #   DIAG=1 tools/build_variant.sh <name> [-DFLAG ...]         the diagnostic library's objects (-DRT_DIAG_VARIANTS)
 name=$1; shift
 cd "$(dirname "$0")/../raytracing_c_amd/csrc" || exit 1
-F="--offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -Wno-unused-function"
+F="--offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -Wno-unused-function ${RAFLAGS--mllvm -greedy-regclass-priority-trumps-globalness=1 -mllvm -amdgpu-prealloc-sgpr-spill-vgprs}"      # RAFLAGS= for the build without the Makefile's register-allocation flags
 tmp=$(mktemp -d)
 srcs="rt_kernels"; [ -n "$DIAG" ] && { srcs="rt_kernels rt_kernels_diag rt_wavefront"; F="$F -DRT_DIAG_VARIANTS"; }
 objs=""
