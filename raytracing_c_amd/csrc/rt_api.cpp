@@ -1887,7 +1887,7 @@ extern "C" int rt_untile(i32 width, i32 height, i32 world, void const *d_all_til
   return untile_on(D, width, height, world, d_all_tiles, d_image, (hipStream_t)stream);
 }
 
-static int ensure_ws_buffers(Workspace &W, int width, int height, size_t tiles_bytes, size_t all_tiles_bytes) {
+static int ensure_ws_buffers(Workspace &W, int width, int height, size_t tiles_bytes, size_t all_tiles_bytes, bool want_linear = true) {
   size_t pixels = (size_t)width * height;
   if (W.accum_elems < pixels * 3) {
     (void)hipFree(W.accum);
@@ -1903,7 +1903,7 @@ static int ensure_ws_buffers(Workspace &W, int width, int height, size_t tiles_b
     W.linear = nullptr;
     W.image_pixels = 0;
     HIP_TRY(hipMalloc(&W.image, pixels * 3));
-    HIP_TRY(hipMalloc(&W.linear, pixels * 3 * sizeof(float)));
+    if (want_linear) HIP_TRY(hipMalloc(&W.linear, pixels * 3 * sizeof(float)));      // (a frame lane has no fp32 output)
     W.image_pixels = pixels;
   }
   if (W.tiles_bytes < tiles_bytes) {
@@ -2339,7 +2339,7 @@ extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samp
     g_multi_counters_valid = false;
   }
   if (!F.stream) HIP_TRY(create_lane_stream(&F.stream, ticket));
-  if (ensure_ws_buffers(F.ws, p.width, p.height, 0, 0) != 0) return -1;
+  if (ensure_ws_buffers(F.ws, p.width, p.height, 0, 0, false) != 0) return -1;
   Workspace &W = F.ws;
   const size_t pixels = (size_t)p.width * p.height;
   RT_Device_Scene *d = cached_scene_locked(D, scene, &F.timing.stamp_ms, &F.timing.upload_ms);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU fuzz (one-off assurance; a script, not collected by pytest): random triangle soups, random cameras (far, near, inside, looking
 away), random frame shapes / sample counts / bounce limits / builders / scene scales; the HIP path through the C-ABI must give
-the oracle's radiance sums and counters bit for bit.    python tests/fuzz_parity.py [seconds] [first seed]   (RT_FUZZ_LARGE=1: frames of 200 ... 900 pixels)"""
+the oracle's radiance sums and counters bit for bit.    python tests/fuzz_parity.py [seconds] [first seed]   (RT_FUZZ_LARGE=1: frames of 200 ... 900 pixels; RT_FUZZ_LANES=1: every frame also through the two frame lanes)"""
 import os
 import sys
 import time
@@ -59,6 +59,13 @@ while time.time() - t0 < budget:
     cn = got["counters"]
     for k in ("paths", "rays", "node_visits", "leaf_visits", "shades", "backgrounds", "textured"):
         ok = ok and want["counters"][k] == getattr(cn, k)
+    if os.environ.get("RT_FUZZ_LANES"):     # ... and the same frame twice through rt_frame_begin / rt_frame_end, both lanes busy
+        ta, outa, ka = rt.frame_begin(hs, w, h, s, b, seed=seed)
+        tb, outb, kb = rt.frame_begin(hs, w, h, s, b, seed=seed ^ 0x5555)
+        ca = rt.frame_end(ta)
+        rt.frame_end(tb)
+        ok = ok and np.array_equal(outa, got["image"]) and ca.rays == cn.rays and ca.node_visits == cn.node_visits
+        ok = ok and np.array_equal(outb, rt.render_frame(hs, w, h, s, b, seed=seed ^ 0x5555)["image"])
     n += 1
     if not ok:
         bad += 1
