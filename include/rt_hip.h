@@ -186,6 +186,8 @@ extern int rt_render_frame(Scene const *scene, Image const *image, isize samples
  * The per-frame scene check is the blocking path's: the sampled stamp at begin, the full content check inside rt_frame_end()
  * while the GPU renders -- a host scene that no longer equals the copy the frame was rendered from is rendered again there,
  * synchronously.  Do not edit (or rt_scene_touch) a scene between the begin and the end of a frame that renders it.
+ * rt_frame_end() waits WITHOUT the library's device lock: two host threads can each keep a frame in flight (a ticket is ended
+ * by one thread, once).
  * With rt_set_devices(n > 1) the frame is rendered inside rt_frame_begin() over the n devices (that pipeline has its own
  * overlap) and rt_frame_end() returns its status. */
 extern int rt_frame_begin(Scene const *scene, Image const *image, isize samples, isize max_bounces);

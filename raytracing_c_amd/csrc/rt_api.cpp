@@ -236,6 +236,7 @@ struct DevPartition {
 struct FrameLane {
   bool        busy = false;                   // begun, not yet ended
   bool        finished = false;               // rendered synchronously inside rt_frame_begin (a multi-device frame): nothing to wait for
+  bool        ending = false;                 // a thread is inside rt_frame_end for this lane, waiting without the mutex
   int         rc = 0;
   hipStream_t stream = nullptr;
   Workspace   ws;
@@ -2361,31 +2362,44 @@ extern "C" int rt_frame_begin(Scene const *scene, Image const *image, isize samp
 
 extern "C" int rt_frame_end(int ticket) {
   Device &D = dev0();
-  std::lock_guard<std::mutex> lock(D.mutex);
-  if (ticket < 0 || ticket >= RT_FRAME_LANES || !D.lanes[ticket].busy) return rt_fail("rt_frame_end: no frame in flight with ticket %d", ticket);
+  std::unique_lock<std::mutex> lock(D.mutex);
+  if (ticket < 0 || ticket >= RT_FRAME_LANES || !D.lanes[ticket].busy || D.lanes[ticket].ending)
+    return rt_fail("rt_frame_end: no frame in flight with ticket %d", ticket);
   FrameLane &F = D.lanes[ticket];
   if (F.finished) { F.busy = false; return F.rc; }
   if (ensure_device(D) != 0) { F.busy = false; return -1; }
   Workspace &W = F.ws;
+  // The wait happens WITHOUT the device's mutex: another host thread can begin (or end) the other lane's frame, or render a
+  // blocking one, meanwhile.  The lane stays busy -- nobody else touches it -- and `ending` refuses a second end of this ticket.
+  F.ending = true;
+  hipStream_t stream = F.stream;
+  const bool verify = F.verify;
+  Scene const *scene = F.scene;
+  lock.unlock();
   // the full content check of the blocking path (render_frame_locked), on this thread, while the GPU renders: the frame came from
   // a copy with fingerprint F.fp; a host scene that no longer has it is rendered again, like there
-  if (F.verify) {
+  uint64_t now = 0;
+  float verify_ms = 0.0f;
+  if (verify) {
     const double t_v = now_ms();
-    const uint64_t now = scene_fingerprint(F.scene);
-    F.timing.verify_ms = (float)(now_ms() - t_v);
-    if (now != F.fp) {
-      (void)hipStreamSynchronize(F.stream);
-      auto it = D.scene_cache.find(F.scene);
-      if (it != D.scene_cache.end() && it->second->full_fp != now) {
-        free_device_scene(it->second);        // (waits for the other lane if that renders from it)
-        D.scene_cache.erase(it);
-      }
-      F.busy = false;
-      F.d = nullptr;
-      return render_frame_locked(F.scene, &F.image, F.p.samples, F.p.max_bounces, nullptr, nullptr, &F.camera, &F.p.seed);
-    }
+    now = scene_fingerprint(scene);
+    verify_ms = (float)(now_ms() - t_v);
   }
-  hipError_t e = hipStreamSynchronize(F.stream);
+  hipError_t e = hipStreamSynchronize(stream);
+  lock.lock();
+  F.ending = false;
+  F.timing.verify_ms = verify_ms;
+  if (ensure_device(D) != 0) { F.busy = false; return -1; }
+  if (verify && now != F.fp) {
+    auto it = D.scene_cache.find(F.scene);
+    if (it != D.scene_cache.end() && it->second->full_fp != now) {
+      free_device_scene(it->second);        // (waits for the other lane if that renders from it)
+      D.scene_cache.erase(it);
+    }
+    F.busy = false;
+    F.d = nullptr;
+    return render_frame_locked(F.scene, &F.image, F.p.samples, F.p.max_bounces, nullptr, nullptr, &F.camera, &F.p.seed);
+  }
   F.busy = false;
   if (e != hipSuccess) return rt_fail("rt_frame_end: %s", hipGetErrorString(e));
   if (copy_image_out(&F.image, W.image, F.p.width, F.p.height, F.stream) != 0) return -1;

@@ -149,3 +149,35 @@ def test_begin_over_rehearsed_devices_renders_at_once(rt):
         assert cnt.rays == ref["counters"].rays
     finally:
         assert rt.lib.rt_set_devices(1, 0) == 0
+
+
+def test_two_host_threads_one_lane_each(rt):
+    """rt_frame_end() waits without the device's mutex: two host threads, each with its own frame in flight, overlap on the GPU
+    and neither sees the other's pixels, counters aside (those describe the frame that ended last)."""
+    import threading
+    from raytracing_c_amd.configs import load_config
+    sp, _ = load_config("spheres")
+    he, _ = load_config("helmet")
+    jobs = [(sp, 96, 64, 8, 4), (he, 80, 48, 8, 8)]
+    refs = [rt.render_frame(hs, w, h, s, b)["image"] for hs, w, h, s, b in jobs]
+    outs = [[], []]
+    errs = []
+
+    def worker(k):
+        hs, w, h, s, b = jobs[k]
+        try:
+            for _ in range(12):
+                t, out, keep = rt.frame_begin(hs, w, h, s, b)
+                rt.frame_end(t)
+                outs[k].append(out)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert len(outs[k]) == 12 and all(np.array_equal(o, refs[k]) for o in outs[k])
